@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels of libccnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ccnet_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define CCNET_LAUNCH_CHECK()                                  \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return CCNET_ELAUNCH; \
+    } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned int)b) << 16);
+}
+// round-to-nearest-even f32 -> bf16 via the hardware convert (NaN safe).
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

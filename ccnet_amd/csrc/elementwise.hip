@@ -1,0 +1,362 @@
+// HBM-/latency-bound helpers: GEGLU (K7), CFG + scheduler step (K9), timestep embedding and fp32 linear
+// (K11), edge convolutions with tiny channel counts, layout converters and the uint8 output mapping.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GEGLU
+__global__ __launch_bounds__(256) void geglu_kernel(const __bf16* x, int ldx, int rows, int C, __bf16* out, int ldo) {
+    const int cols = C / 8;
+    const long long total = (long long)rows * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / cols), c = (int)(idx % cols) * 8;
+        float av[8], gv[8];
+        unpack8(*(const u32x4*)(x + (long long)r * ldx + c), av);
+        unpack8(*(const u32x4*)(x + (long long)r * ldx + C + c), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] *= 0.5f * gv[e] * (1.0f + erff(gv[e] * 0.70710678118654752f));
+        *(u32x4*)(out + (long long)r * ldo + c) = pack8(av);
+    }
+}
+
+// ------------------------------------------------------------------ CFG combine + DDIM / DDPM step (fp32)
+__global__ __launch_bounds__(256) void cfg_step_kernel(const float* mo, int cfg_mode, float g, const float* coef,
+                                                       const float* noise, float* sample, float* x0_out, int B,
+                                                       int per_image) {
+    const float sa = coef[0], sb = coef[1], c_x0 = coef[2], c_2 = coef[3], sigma = coef[4];
+    const bool clip = coef[5] != 0.f;
+    const int ptype = (int)coef[6];
+    const bool ddpm = coef[7] != 0.f;
+    const long long total = (long long)B * per_image;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float pred;
+        if (cfg_mode == 0) {
+            pred = mo[total + i];
+        } else if (cfg_mode == 1) {
+            pred = mo[i];
+        } else if (cfg_mode == 2) {
+            const float u = mo[i], t = mo[total + i];
+            pred = u + g * (t - u);
+        } else {
+            pred = mo[i];  // no CFG batch (log_controlnet_samples path)
+        }
+        const float x = sample[i];
+        float x0, eps;
+        if (ptype == 2) { x0 = sa * x - sb * pred; eps = sa * pred + sb * x; }
+        else if (ptype == 0) { x0 = (x - sb * pred) / sa; eps = pred; }
+        else { x0 = pred; eps = (x - sa * x0) / sb; }
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float prev;
+        if (ddpm) {
+            prev = c_x0 * x0 + c_2 * x;
+            if (noise) prev += sigma * noise[i];
+        } else {
+            prev = c_x0 * x0 + c_2 * eps;
+            if (noise) prev += sigma * noise[i];
+        }
+        sample[i] = prev;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+// ------------------------------------------------------------------ timestep embedding, fp32 linear
+__global__ void temb_kernel(const float* t, int nt, int B, int dim, const float* freqs, float* out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, c = i % dim;
+    const float tv = t[nt == 1 ? 0 : b];
+    float v = 0.f;
+    if (c < 2 * half) {
+        const int k = c < half ? c : c - half;
+        const float arg = tv * freqs[k];
+        v = c < half ? cosf(arg) : sinf(arg);
+    }
+    out[i] = v;
+}
+
+// one wave per output feature n, all batch rows (B <= 64 per launch chunk of 8 kept in registers)
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int ldx, int B, int K, const float* w,
+                                                         const float* bias, int Nout, int silu_in, int silu_out,
+                                                         const float* add, int ldadd, float* out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= Nout) return;
+    const float* wr = w + (long long)n * K;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float wv = wr[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (b0 + j < B) {
+                    float xv = x[(long long)(b0 + j) * ldx + k];
+                    if (silu_in) xv = silu_f(xv);
+                    acc[j] += wv * xv;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0 && b0 + j < B) {
+                float v = s + (bias ? bias[n] : 0.f);
+                if (silu_out) v = silu_f(v);
+                if (add) v += add[(long long)(b0 + j) * ldadd + n];
+                out[(long long)(b0 + j) * ldo + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ edge convolutions
+// conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16; thread = (pixel, 8 couts).
+__global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int Nsrc, int N, int Cin, int H, int W,
+                                                            const float* w, const float* bias, int Cout, int stride,
+                                                            int act, const __bf16* res, int Nres, int ldres,
+                                                            __bf16* out, int ldo, int Hout, int Wout) {
+    extern __shared__ float sw[];  // [Cout][Cin*9] + bias[Cout]
+    const int K = Cin * 9;
+    for (int i = threadIdx.x; i < Cout * K; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) sw[Cout * K + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int cg = (ldo) / 8;  // write every 8-channel group of the padded row (zeros beyond Cout)
+    const long long total = (long long)N * Hout * Wout * cg;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % cg);
+        const long long pixel = idx / cg;
+        const int ox = (int)(pixel % Wout), oy = (int)((pixel / Wout) % Hout), n = (int)(pixel / ((long long)Wout * Hout));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (g * 8 < Cout) {
+            float xin[72];
+            const float* xb = x + (long long)(n % Nsrc) * Cin * H * W;
+            for (int c = 0; c < Cin; ++c)
+#pragma unroll
+                for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const int iy = oy * stride - 1 + kr, ix = ox * stride - 1 + ks;
+                        xin[c * 9 + kr * 3 + ks] =
+                            ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xb[((long long)c * H + iy) * W + ix] : 0.f;
+                    }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int co = g * 8 + e;
+                if (co < Cout) {
+                    float s = sw[Cout * K + co];
+                    const float* wr = sw + co * K;
+                    for (int k = 0; k < K; ++k) s += wr[k] * xin[k];
+                    v[e] = act == 1 ? silu_f(s) : s;
+                }
+            }
+            if (res) {
+                float r[8];
+                const long long rpix = ((long long)(n % Nres) * Hout + oy) * Wout + ox;
+                unpack8(*(const u32x4*)(res + rpix * ldres + g * 8), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (g * 8 + e < Cout) v[e] += r[e];
+            }
+        }
+        *(u32x4*)(out + pixel * ldo + g * 8) = pack8(v);
+    }
+}
+
+// conv_out_small: NHWC bf16 -> fp32 NCHW, Cout <= 8, 3x3 stride 1 pad 1; one wave per output pixel.
+__global__ __launch_bounds__(256) void conv_out_small_kernel(const __bf16* x, int ldx, int N, int H, int W, int Cin,
+                                                             const __bf16* w, const float* bias, int Cout,
+                                                             float* out) {
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)N * H * W;
+    const int cols = Cin / 8;
+    for (long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pixel < npix; pixel += (long long)gridDim.x * 4) {
+        const int ox = (int)(pixel % W), oy = (int)((pixel / W) % H), n = (int)(pixel / ((long long)W * H));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;  // wave-uniform
+            const __bf16* xp = x + (((long long)n * H + iy) * W + ix) * ldx;
+            for (int col = lane; col < cols; col += 64) {
+                float xv[8];
+                unpack8(*(const u32x4*)(xp + col * 8), xv);
+#pragma unroll
+                for (int co = 0; co < 8; ++co) {
+                    if (co < Cout) {
+                        float wv[8];
+                        unpack8(*(const u32x4*)(w + ((long long)co * 9 + tap) * Cin + col * 8), wv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[co] += xv[e] * wv[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            if (co < Cout) {
+                const float s = wave_sum(acc[co]);
+                if (lane == 0) out[(((long long)n * Cout + co) * H + oy) * W + ox] = s + (bias ? bias[co] : 0.f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ layout converters / uint8 mapping
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int N, int C, int HW, __bf16* out, int ldo) {
+    // tile transpose through LDS: 64 pixels x 64 channels per block
+    __shared__ float t[64][65];
+    const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, p = p0 + tx;
+        t[cc][tx] = (c < C && p < HW) ? x[((long long)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    unsigned short* o = (unsigned short*)out;
+    for (int pp = ty; pp < 64; pp += 4) {
+        const int p = p0 + pp, c = c0 + tx;
+        if (p < HW && c < ldo) o[((long long)n * HW + p) * ldo + c] = f32_to_bf16_bits(c < C ? t[tx][pp] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const __bf16* x, int ldx, int N, int C, int HW, float* out) {
+    __shared__ float t[64][65];
+    const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const unsigned short* xi = (const unsigned short*)x;
+    for (int pp = ty; pp < 64; pp += 4) {
+        const int p = p0 + pp, c = c0 + tx;
+        t[pp][tx] = (p < HW && c < C) ? bf16_bits_to_f32(xi[((long long)n * HW + p) * ldx + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int c = c0 + cc, p = p0 + tx;
+        if (c < C && p < HW) out[((long long)n * C + c) * HW + p] = t[tx][cc];
+    }
+}
+
+__global__ __launch_bounds__(256) void to_uint8_kernel(const float* x, int N, int C, int HW, uint8_t* out) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, p = i % HW;
+        float v = (x[n * C * HW + p] + 1.0f) * 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i] = (uint8_t)rintf(v * 255.0f);
+    }
+}
+
+int grid_for(long long total, int per_block) {
+    long long g = (total + per_block - 1) / per_block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" const char* ccnet_strerror(int code) {
+    switch (code) {
+        case CCNET_OK: return "ok";
+        case CCNET_EINVAL: return "invalid argument (shape, alignment or null pointer)";
+        case CCNET_EUNSUP: return "unsupported configuration";
+        case CCNET_ELAUNCH: return "HIP launch failed";
+        case CCNET_EWS: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+extern "C" int ccnet_version(void) { return 1; }
+extern "C" const char* ccnet_arch(void) { return "gfx950"; }
+
+extern "C" int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || ldx < 2 * C) return CCNET_EINVAL;
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((long long)rows * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, ldx, rows, C, (__bf16*)out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_cfg_scheduler_step(const float* model_out, int cfg_mode, float guidance, const float* coef,
+                                        const float* noise, float* sample, float* x0_out, int B, int per_image,
+                                        void* stream) {
+    if (!model_out || !coef || !sample || B <= 0 || per_image <= 0 || cfg_mode < 0 || cfg_mode > 3) return CCNET_EINVAL;
+    hipLaunchKernelGGL(cfg_step_kernel, dim3(grid_for((long long)B * per_image, 256)), dim3(256), 0,
+                       (hipStream_t)stream, model_out, cfg_mode, guidance, coef, noise, sample, x0_out, B, per_image);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_timestep_embedding(const float* t, int nt, int B, int dim, const float* freqs, float* out,
+                                        void* stream) {
+    if (!t || !out || !freqs || B <= 0 || dim <= 1 || (nt != 1 && nt != B)) return CCNET_EINVAL;
+    hipLaunchKernelGGL(temb_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, nt, B, dim,
+                       freqs, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_linear_f32(const float* x, int ldx, int B, int K, const float* w, const float* bias, int Nout,
+                                int silu_in, int silu_out, const float* add, int ldadd, float* out, int ldo,
+                                void* stream) {
+    if (!x || !w || !out || B <= 0 || K <= 0 || Nout <= 0) return CCNET_EINVAL;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((Nout + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, B, K, w,
+                       bias, Nout, silu_in, silu_out, add, ldadd, out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_conv_in_small(const float* x, int Nsrc, int N, int Cin, int H, int W, const float* w,
+                                   const float* bias, int Cout, int stride, int act, const void* res, int Nres,
+                                   int ldres, void* out, int ldo, int Hout, int Wout, void* stream) {
+    if (!x || !w || !out || Nsrc <= 0 || N <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || (ldo % 8) || ldo < Cout)
+        return CCNET_EINVAL;
+    if (stride != 1 && stride != 2) return CCNET_EUNSUP;
+    if (res && (Nres <= 0 || (ldres % 8))) return CCNET_EINVAL;
+    if (Hout != (H + 2 - 3) / stride + 1 || Wout != (W + 2 - 3) / stride + 1) return CCNET_EINVAL;
+    const size_t lds = (size_t)(Cout * Cin * 9 + Cout) * sizeof(float);
+    if (lds > 60000) return CCNET_EUNSUP;
+    const long long total = (long long)N * Hout * Wout * (ldo / 8);
+    hipLaunchKernelGGL(conv_in_small_kernel, dim3(grid_for(total, 256)), dim3(256), lds, (hipStream_t)stream, x, Nsrc,
+                       N, Cin, H, W, w, bias, Cout, stride, act, (const __bf16*)res, Nres, ldres, (__bf16*)out, ldo,
+                       Hout, Wout);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_conv_out_small(const void* x, int ldx, int N, int H, int W, int Cin, const void* w,
+                                    const float* bias, int Cout, float* out, void* stream) {
+    if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8) || (ldx % 8) || Cout <= 0 || Cout > 8)
+        return CCNET_EINVAL;
+    hipLaunchKernelGGL(conv_out_small_kernel, dim3(grid_for((long long)N * H * W, 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)x, ldx, N, H, W, Cin, (const __bf16*)w, bias, Cout, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_nchw_f32_to_nhwc_bf16(const float* x, int N, int C, int HW, void* out, int ldo, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || HW <= 0 || ldo < C || N > 65535) return CCNET_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (ldo + 63) / 64, N), dim3(256), 0, (hipStream_t)stream,
+                       x, N, C, HW, (__bf16*)out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_nhwc_bf16_to_nchw_f32(const void* x, int ldx, int N, int C, int HW, float* out, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || HW <= 0 || ldx < C || N > 65535) return CCNET_EINVAL;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 63) / 64, (C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, ldx, N, C, HW, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return CCNET_EINVAL;
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for((long long)N * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, N,
+                       C, HW, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}

@@ -1,0 +1,358 @@
+// K1/K2/K8/K10: implicit-GEMM convolution / linear layer on bf16 MFMA for gfx950.
+//
+// Data layout in HBM: activations NHWC bf16 (a "pixel row" of C channels is contiguous), weights
+// [Cout][R*R*Cin] bf16 with K ordered (kr, ks, cin) so a 64-channel K-slice of one filter tap is one
+// contiguous 128-byte run for both operands.  One workgroup computes a (64*WM pixels) x (64*WN couts)
+// tile; every wave owns a 64x64 sub-tile = 2x2 accumulators of v_mfma_f32_32x32x16_bf16 with the
+// weights as the A operand (rows = cout) and the pixels as the B operand (cols = pixel), so that each
+// lane ends up with 4 consecutive couts of one pixel per accumulator quad.
+//
+// K loop: one step = 64 channels of one tap.  Operand tiles are fetched with raw buffer loads (the
+// hardware range check returns 0 for the padding taps and for rows beyond M / Cout, so the gather has no
+// branches), written to LDS in an XOR-swizzled [row][64] image (conflict-free ds_read_b128 fragment
+// reads) and double-buffered: the loads of step k+1 are issued before the MFMAs of step k and written
+// after them, one barrier per step.
+//
+// Epilogue: accumulators go through a per-wave fp32 LDS patch so that bias / time-embedding / residual
+// reads and the bf16 stores are 16 B per lane and 128 B contiguous per pixel row.
+#include "common.h"
+#include <vector>
+
+namespace {
+
+struct ConvArgs {
+    const __bf16* x1; const __bf16* x2; const __bf16* w;
+    const float* bias; const float* rowvec; const __bf16* res1; const __bf16* res2;
+    __bf16* out; __bf16* out2;
+    int N, Hin, Win, Hout, Wout, C1, C2, Cout, R, stride, pad, ups;
+    int ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec, act;
+    float scale;
+    int M, HWout, KT, CT1, CT, tilesN, tiles;
+    long long sx1, sw, so;
+    unsigned x1_bytes, x2_bytes, w_bytes;
+};
+
+constexpr unsigned OOB = 0x80000000u;  // beyond any num_records we accept (< 2^31 bytes)
+
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
+    constexpr int RPP = NT / 8;            // tile rows covered by one pass of all threads (8 x 16 B per row)
+    constexpr int NX = BM / RPP, NW = BN / RPP;
+    constexpr int STAGE = (BM + BN) * 128;  // bytes per pipeline stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    // XCD-aware tile order: blocks b, b+8, ... share an L2, give them consecutive tiles (bijective form).
+    int tile;
+    {
+        const int nwg = a.tiles, b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+    const int z = blockIdx.z;
+
+    const __bf16* x1 = a.x1 + (long long)z * a.sx1;
+    const __bf16* wp = a.w + (long long)z * a.sw;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)x1, 0, a.x1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, a.w_bytes, 0x00020000);
+
+    const int lrow = tid >> 3, lchunk = tid & 7;
+
+    // per-thread gather rows: image index and top-left input coordinate of each output pixel
+    int xn[NX], xiy0[NX], xix0[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int m = m0 + lrow + i * RPP;
+        if (m < a.M) {
+            const int n = m / a.HWout, rem = m - n * a.HWout;
+            const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+            xn[i] = n; xiy0[i] = oy * a.stride - a.pad; xix0[i] = ox * a.stride - a.pad;
+        } else {
+            xn[i] = -1; xiy0[i] = 0; xix0[i] = 0;
+        }
+    }
+    unsigned woff[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int n = n0 + lrow + i * RPP;
+        woff[i] = n < a.Cout ? (unsigned)(n * a.ldw + lchunk * 8) * 2u : OOB;
+    }
+    const int Hl = a.Hin * a.ups, Wl = a.Win * a.ups, ush = a.ups >> 1;
+
+    int pix[NX];
+    auto set_tap = [&](int tap) {
+        const int kr = tap / a.R, ks = tap - kr * a.R;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int iy = xiy0[i] + kr, ix = xix0[i] + ks;
+            const bool ok = xn[i] >= 0 && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+            pix[i] = ok ? (xn[i] * a.Hin + (iy >> ush)) * a.Win + (ix >> ush) : -1;
+        }
+    };
+
+    u32x4 xr[NX], wr[NW];
+    int tap_n = 0, cc_n = 0, kt_n = 0;  // K-step that the next issue_loads() fetches
+    auto issue_loads = [&]() {
+        if (cc_n == 0) set_tap(tap_n);
+        if (cc_n < a.CT1) {
+            const unsigned co = (unsigned)(cc_n * 64 + lchunk * 8);
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                xr[i] = buf_load16(r1, pix[i] < 0 ? OOB : ((unsigned)pix[i] * (unsigned)a.ldx1 + co) * 2u);
+        } else {
+            const unsigned co = (unsigned)((cc_n - a.CT1) * 64 + lchunk * 8);
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+                xr[i] = buf_load16(r2, pix[i] < 0 ? OOB : ((unsigned)pix[i] * (unsigned)a.ldx2 + co) * 2u);
+        }
+        const unsigned kb = (unsigned)kt_n * 128u;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wr[i] = buf_load16(rw, woff[i] == OOB ? OOB : woff[i] + kb);
+        ++kt_n;
+        if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
+    };
+    auto store_stage = [&](int s) {
+        char* xb = smem + s * STAGE;
+        char* wb = xb + BM * 128;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int r = lrow + i * RPP;
+            *(u32x4*)(xb + r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4)) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int r = lrow + i * RPP;
+            *(u32x4*)(wb + r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4)) = wr[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int swz = (l31 >> 1) & 7;
+    const int xrow_off = (wm * 64 + l31) * 128, wrow_off = (wn * 64 + l31) * 128;
+    auto compute = [&](int s) {
+        const char* xb = smem + s * STAGE;
+        const char* wb = xb + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int co = ((2 * ks + hh) ^ swz) << 4;
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * 128 + co);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * 128 + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    issue_loads();
+    store_stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const bool more = kt + 1 < a.KT;
+        if (more) issue_loads();
+        compute(kt & 1);
+        if (more) store_stage((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    float* ep = (float*)smem + wave * (32 * 68);
+    const int lr = lane >> 3, lc = lane & 7;
+    const int ncol = n0 + wn * 64 + lc * 8;
+    const bool nok = ncol < a.Cout;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (a.bias && nok) {
+        const f32x4 b0 = *(const f32x4*)(a.bias + ncol), b1 = *(const f32x4*)(a.bias + ncol + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+    __bf16* outp = a.out + (long long)z * a.so;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *(f32x4*)(ep + l31 * 68 + i * 32 + 8 * q + 4 * hh) = v;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = rr * 8 + lr;
+            const int m = m0 + wm * 64 + j * 32 + row;
+            const f32x4 v0 = *(const f32x4*)(ep + row * 68 + lc * 8);
+            const f32x4 v1 = *(const f32x4*)(ep + row * 68 + lc * 8 + 4);
+            if (m < a.M && nok) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+                if (a.rowvec) {
+                    const float* rv = a.rowvec + (long long)(m / a.HWout) * a.ld_rowvec + ncol;
+                    const f32x4 t0 = *(const f32x4*)rv, t1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+                }
+                if (a.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= a.scale;
+                if (a.res1) {
+                    float r[8];
+                    unpack8(*(const u32x4*)(a.res1 + (long long)m * a.ldres1 + ncol), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                *(u32x4*)(outp + (long long)m * a.ldo + ncol) = pack8(v);
+                if (a.out2) {
+                    float r[8];
+                    unpack8(*(const u32x4*)(a.res2 + (long long)m * a.ldres2 + ncol), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    *(u32x4*)(a.out2 + (long long)m * a.ldo2 + ncol) = pack8(v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------- profiling hooks
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+
+template <int WM, int WN>
+int launch(const ConvArgs& a, int batch, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS) != hipSuccess)
+            return CCNET_ELAUNCH;
+        attr_set = true;
+    }
+    ConvArgs b = a;
+    b.tilesN = (a.Cout + BN - 1) / BN;
+    b.tiles = ((a.M + BM - 1) / BM) * b.tilesN;
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN>), dim3(b.tiles, 1, batch), dim3(NT), LDS, st, b);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+}  // namespace
+
+extern "C" int ccnet_prof_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_prof_collect(double* ms, double* flops, int64_t* launches) {
+    double tms = 0, tf = 0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        if (hipEventSynchronize(g_prof[i].e1) != hipSuccess) return CCNET_ELAUNCH;
+        float t = 0;
+        if (hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1) != hipSuccess) return CCNET_ELAUNCH;
+        tms += t;
+        tf += g_prof[i].flops;
+    }
+    if (ms) *ms = tms;
+    if (flops) *flops = tf;
+    if (launches) *launches = (int64_t)g_prof_used;
+    g_prof_used = 0;
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
+    if (!p || !p->x1 || !p->w || !p->out) return CCNET_EINVAL;
+    if (p->R != 1 && p->R != 3) return CCNET_EUNSUP;
+    if (p->ups != 1 && p->ups != 2) return CCNET_EUNSUP;
+    if (p->C1 <= 0 || (p->C1 % 64) || (p->C2 % 64) || p->C2 < 0 || (p->C2 > 0 && !p->x2)) return CCNET_EINVAL;
+    if ((p->Cout % 8) || p->Cout <= 0) return CCNET_EINVAL;
+    if ((p->ldx1 % 8) || (p->ldw % 8) || (p->ldo % 8)) return CCNET_EINVAL;
+    if (p->C2 > 0 && (p->ldx2 % 8)) return CCNET_EINVAL;
+    if (p->res1 && (p->ldres1 % 8)) return CCNET_EINVAL;
+    if ((p->res2 != nullptr) != (p->out2 != nullptr)) return CCNET_EINVAL;
+    if (p->out2 && ((p->ldo2 % 8) || (p->ldres2 % 8))) return CCNET_EINVAL;
+    if (p->rowvec && (p->ld_rowvec % 4)) return CCNET_EINVAL;
+    if (p->N <= 0 || p->Hin <= 0 || p->Win <= 0 || p->Hout <= 0 || p->Wout <= 0 || p->stride <= 0) return CCNET_EINVAL;
+    const int batch = p->batch > 1 ? p->batch : 1;
+    if (batch > 1 && (p->R != 1 || p->C2 != 0)) return CCNET_EUNSUP;
+    // every gathered tap must fall inside the (upsampled) input or be a padding tap: checked in-kernel by
+    // coordinates; here make sure the implied geometry is self-consistent so no row can index past x1/x2.
+    const long long Hl = (long long)p->Hin * p->ups, Wl = (long long)p->Win * p->ups;
+    if ((long long)(p->Hout - 1) * p->stride - p->pad >= Hl || (long long)(p->Wout - 1) * p->stride - p->pad >= Wl)
+        return CCNET_EINVAL;
+
+    ConvArgs a{};
+    a.x1 = (const __bf16*)p->x1; a.x2 = (const __bf16*)p->x2; a.w = (const __bf16*)p->w;
+    a.bias = p->bias; a.rowvec = p->rowvec; a.res1 = (const __bf16*)p->res1; a.res2 = (const __bf16*)p->res2;
+    a.out = (__bf16*)p->out; a.out2 = (__bf16*)p->out2;
+    a.N = p->N; a.Hin = p->Hin; a.Win = p->Win; a.Hout = p->Hout; a.Wout = p->Wout;
+    a.C1 = p->C1; a.C2 = p->C2; a.Cout = p->Cout; a.R = p->R; a.stride = p->stride; a.pad = p->pad; a.ups = p->ups;
+    a.ldx1 = p->ldx1; a.ldx2 = p->ldx2; a.ldw = p->ldw; a.ldo = p->ldo; a.ldo2 = p->ldo2;
+    a.ldres1 = p->ldres1; a.ldres2 = p->ldres2; a.ld_rowvec = p->ld_rowvec; a.act = p->act; a.scale = p->scale;
+    a.M = p->N * p->Hout * p->Wout; a.HWout = p->Hout * p->Wout;
+    a.CT1 = p->C1 / 64; a.CT = (p->C1 + p->C2) / 64; a.KT = p->R * p->R * a.CT;
+    a.sx1 = p->sx1; a.sw = p->sw; a.so = p->so;
+    const long long xb1 = ((long long)p->N * p->Hin * p->Win - 1) * p->ldx1 * 2 + (long long)p->C1 * 2;
+    const long long xb2 = p->C2 ? ((long long)p->N * p->Hin * p->Win - 1) * p->ldx2 * 2 + (long long)p->C2 * 2 : 0;
+    const long long wb = ((long long)p->Cout - 1) * p->ldw * 2 + (long long)a.KT * 128;
+    if (xb1 >= 0x7fffffffLL || xb2 >= 0x7fffffffLL || wb >= 0x7fffffffLL) return CCNET_EUNSUP;
+    a.x1_bytes = (unsigned)xb1; a.x2_bytes = (unsigned)xb2; a.w_bytes = (unsigned)wb;
+
+    hipStream_t st = (hipStream_t)stream;
+    ProfRec* rec = nullptr;
+    if (g_prof_on) {
+        if (g_prof_used == g_prof.size()) {
+            ProfRec r{};
+            if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return CCNET_ELAUNCH;
+            g_prof.push_back(r);
+        }
+        rec = &g_prof[g_prof_used++];
+        rec->flops = 2.0 * a.M * (double)p->Cout * (double)(a.KT * 64) * batch;
+        hipEventRecord(rec->e0, st);
+    }
+    // tile choice: 128x128 when Cout fills it, else 64-wide cout tiles; small problems take smaller
+    // pixel tiles so the grid still covers the 256 CUs.
+    int rc;
+    const long long t22 = (long long)((a.M + 127) / 128) * ((p->Cout + 127) / 128) * batch;
+    const bool n128 = (p->Cout % 128) == 0 || p->Cout >= 512;
+    if (n128 && t22 >= 384)
+        rc = launch<2, 2>(a, batch, st);
+    else if ((long long)((a.M + 127) / 128) * ((p->Cout + 63) / 64) * batch >= 384)
+        rc = launch<2, 1>(a, batch, st);
+    else
+        rc = launch<1, 1>(a, batch, st);
+    if (rec) hipEventRecord(rec->e1, st);
+    return rc;
+}

@@ -1,0 +1,217 @@
+// K3 GroupNorm(+SiLU) and K6 LayerNorm over NHWC bf16 rows, fp32 statistics.  HBM-bound kernels:
+// every access is 16 B per lane (8 bf16 channels) and consecutive lanes read consecutive channel chunks.
+//
+// GroupNorm, NHWC: a group is C/groups adjacent channels of every pixel of one image.
+//   pass 1 (gn_stats): grid (chunks, N); a block streams its pixel range for all channels, each thread
+//     owning a fixed 8-channel column so it accumulates per-channel (sum, sumsq) in registers; columns are
+//     folded into per-group partials through LDS and written to the workspace [N][chunks][groups][2]
+//     as (mean, M2) of that chunk;
+//   pass 2 (gn_apply): every block merges the chunk partials of its image with Chan's parallel-variance
+//     formula, builds per-channel scale/shift in LDS and streams x*A+B (+SiLU) -> bf16.
+//   Two reads + one write per element (6 B vs the 4 B algorithmic minimum); the second read normally hits
+//   the 256 MiB Infinity Cache.  A channel concat of two tensors (x1 | x2) is read in place.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAXC = 4096;
+
+struct GnArgs {
+    const __bf16* x1; const __bf16* x2; int ldx1, ldx2, C1, C2, C, N, HW, groups, cpg, chunks, ppc;
+    float eps; const float* gamma; const float* beta; int silu; __bf16* out; int ldo; float* ws;
+};
+
+__device__ __forceinline__ u32x4 gn_load(const GnArgs& a, long long pixrow, int c) {
+    // c = first channel of an 8-channel column
+    if (c < a.C1) return *(const u32x4*)(a.x1 + pixrow * a.ldx1 + c);
+    return *(const u32x4*)(a.x2 + pixrow * a.ldx2 + (c - a.C1));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
+    __shared__ float s_sum[GN_MAXC], s_sq[GN_MAXC];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int cols = a.C / 8;
+    const int p0 = chunk * a.ppc, p1 = min(a.HW, p0 + a.ppc);
+    for (int c = tid; c < a.C; c += GN_THREADS) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    const int cstride = cols < GN_THREADS ? cols : GN_THREADS;  // columns covered per sweep
+    const int rows_par = GN_THREADS / cstride;                   // pixel rows processed in parallel
+    const int my_col = tid % cstride, my_row = tid / cstride;
+    if (my_row < rows_par) {
+        for (int col = my_col; col < cols; col += cstride) {
+            float s[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+            for (int p = p0 + my_row; p < p1; p += rows_par) {
+                float f[8];
+                unpack8(gn_load(a, (long long)n * a.HW + p, col * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(&s_sum[col * 8 + e], s[e]);
+                atomicAdd(&s_sq[col * 8 + e], q[e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < a.groups) {
+        float s = 0.f, q = 0.f;
+        for (int c = tid * a.cpg; c < (tid + 1) * a.cpg; ++c) { s += s_sum[c]; q += s_sq[c]; }
+        const float cnt = (float)((p1 - p0) * a.cpg);
+        const float mean = s / cnt;
+        float* w = a.ws + (((long long)n * a.chunks + chunk) * a.groups + tid) * 2;
+        w[0] = mean;
+        w[1] = fmaxf(q - s * mean, 0.f);  // M2 of this chunk
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
+    __shared__ float s_a[GN_MAXC], s_b[GN_MAXC];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    if (tid < a.groups) {
+        float mean = 0.f, m2 = 0.f, cnt = 0.f;
+        for (int k = 0; k < a.chunks; ++k) {
+            const float* w = a.ws + (((long long)n * a.chunks + k) * a.groups + tid) * 2;
+            const int q0 = k * a.ppc, q1 = min(a.HW, q0 + a.ppc);
+            const float cb = (float)((q1 - q0) * a.cpg);
+            const float delta = w[0] - mean, tot = cnt + cb;
+            mean += delta * (cb / tot);
+            m2 += w[1] + delta * delta * (cnt * cb / tot);
+            cnt = tot;
+        }
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(m2 / cnt + a.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C; c += GN_THREADS) {
+        const int g = c / a.cpg;
+        const float A = s_rstd[g] * a.gamma[c];
+        s_a[c] = A;
+        s_b[c] = a.beta[c] - s_mean[g] * A;
+    }
+    __syncthreads();
+    const int cols = a.C / 8;
+    const int p0 = chunk * a.ppc, p1 = min(a.HW, p0 + a.ppc);
+    const int total = (p1 - p0) * cols;
+    for (int idx = tid; idx < total; idx += GN_THREADS) {
+        const int p = p0 + idx / cols, col = idx % cols;
+        const long long row = (long long)n * a.HW + p;
+        float f[8];
+        unpack8(gn_load(a, row, col * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = f[e] * s_a[col * 8 + e] + s_b[col * 8 + e];
+            f[e] = a.silu ? silu_f(v) : v;
+        }
+        *(u32x4*)(a.out + row * a.ldo + col * 8) = pack8(f);
+    }
+}
+
+void gn_plan(int N, int HW, int C, int& chunks, int& ppc) {
+    // aim for >= ~1024 blocks overall but at least 16 pixels (and ~32 KB) per block
+    int want = (1024 + N - 1) / N;
+    int min_ppc = 16;
+    while ((long long)min_ppc * C * 2 < 32768 && min_ppc < HW) min_ppc *= 2;
+    int maxchunks = (HW + min_ppc - 1) / min_ppc;
+    chunks = want < maxchunks ? want : maxchunks;
+    if (chunks < 1) chunks = 1;
+    ppc = (HW + chunks - 1) / chunks;
+    chunks = (HW + ppc - 1) / ppc;
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+constexpr int LN_MAXCH = 4;  // 8-channel chunks per lane -> C <= 2048
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const __bf16* x, int ldx, int rows, int C, float eps,
+                                                        const float* gamma, const float* beta, __bf16* out,
+                                                        int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int cols = C / 8;
+    float f[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int col = lane + k * 64;
+        if (col < cols) {
+            unpack8(*(const u32x4*)(x + (long long)row * ldx + col * 8), f[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[k][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int col = lane + k * 64;
+        if (col < cols) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXCH; ++k) {
+        const int col = lane + k * 64;
+        if (col < cols) {
+            float o[8];
+            const f32x4 g0 = *(const f32x4*)(gamma + col * 8), g1 = *(const f32x4*)(gamma + col * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + col * 8), b1 = *(const f32x4*)(beta + col * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (f[k][e] - mean) * rstd * g0[e] + b0[e];
+                o[4 + e] = (f[k][4 + e] - mean) * rstd * g1[e] + b1[e];
+            }
+            *(u32x4*)(out + (long long)row * ldo + col * 8) = pack8(o);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ccnet_groupnorm_workspace_bytes(int N, int HW, int C, int groups) {
+    if (N <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+    int chunks, ppc;
+    gn_plan(N, HW, C, chunks, ppc);
+    return (size_t)N * chunks * groups * 2 * sizeof(float);
+}
+
+extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2, int N,
+                                    int HW, int groups, float eps, const float* gamma, const float* beta,
+                                    int silu, void* out, int ldo, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    if (!x1 || !out || !gamma || !beta || !workspace) return CCNET_EINVAL;
+    if (C2 < 0 || (C2 > 0 && !x2)) return CCNET_EINVAL;
+    const int C = C1 + C2;
+    if (N <= 0 || HW <= 0 || C1 <= 0 || groups <= 0 || groups > 64 || (C % groups)) return CCNET_EINVAL;
+    if ((C1 % 8) || (C2 % 8) || (ldx1 % 8) || (ldo % 8) || (C2 > 0 && (ldx2 % 8))) return CCNET_EINVAL;
+    if (C > GN_MAXC) return CCNET_EUNSUP;
+    GnArgs a{};
+    a.x1 = (const __bf16*)x1; a.x2 = (const __bf16*)x2; a.ldx1 = ldx1; a.ldx2 = ldx2; a.C1 = C1; a.C2 = C2; a.C = C;
+    a.N = N; a.HW = HW; a.groups = groups; a.cpg = C / groups; a.eps = eps; a.gamma = gamma; a.beta = beta;
+    a.silu = silu; a.out = (__bf16*)out; a.ldo = ldo; a.ws = (float*)workspace;
+    gn_plan(N, HW, C, a.chunks, a.ppc);
+    if (workspace_bytes < (size_t)N * a.chunks * groups * 2 * sizeof(float)) return CCNET_EWS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, N), dim3(GN_THREADS), 0, st, a);
+    CCNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(a.chunks, N), dim3(GN_THREADS), 0, st, a);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_layernorm_bf16(const void* x, int ldx, int rows, int C, float eps, const float* gamma,
+                                    const float* beta, void* out, int ldo, void* stream) {
+    if (!x || !out || !gamma || !beta) return CCNET_EINVAL;
+    if (rows <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8)) return CCNET_EINVAL;
+    if (C > LN_MAXCH * 64 * 8) return CCNET_EUNSUP;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, ldx, rows, C, eps, gamma, beta, (__bf16*)out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}

@@ -1,0 +1,89 @@
+"""ctypes binding of libccnet_hip.so (the C ABI declared in include/ccnet_hip.h).
+
+The library is the only compute path of this package: there is no CPU or eager-PyTorch fallback.
+`load()` raises if the shared object is missing, and every op raises `CcnetError` on a non-zero
+return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libccnet_hip.so"
+
+EXPORTS = [
+    "ccnet_strerror", "ccnet_version", "ccnet_arch", "ccnet_conv_gemm_bf16", "ccnet_conv_in_small",
+    "ccnet_conv_out_small", "ccnet_groupnorm_workspace_bytes", "ccnet_groupnorm_bf16", "ccnet_layernorm_bf16",
+    "ccnet_geglu_bf16", "ccnet_attention_d64_bf16", "ccnet_softmax_rows_bf16", "ccnet_timestep_embedding",
+    "ccnet_linear_f32", "ccnet_cfg_scheduler_step", "ccnet_nchw_f32_to_nhwc_bf16", "ccnet_nhwc_bf16_to_nchw_f32",
+    "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect",
+]
+
+
+class CcnetError(RuntimeError):
+    pass
+
+
+class ConvParams(C.Structure):
+    """Mirror of `ccnet_conv_params` (include/ccnet_hip.h)."""
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
+        ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("C1", C.c_int32), ("C2", C.c_int32), ("Cout", C.c_int32), ("R", C.c_int32), ("stride", C.c_int32),
+        ("pad", C.c_int32), ("ups", C.c_int32),
+        ("ldx1", C.c_int32), ("ldx2", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldo2", C.c_int32),
+        ("ldres1", C.c_int32), ("ldres2", C.c_int32), ("ld_rowvec", C.c_int32),
+        ("act", C.c_int32), ("scale", C.c_float), ("batch", C.c_int32),
+        ("sx1", C.c_int64), ("sw", C.c_int64), ("so", C.c_int64), ("reserved", C.c_int32 * 4),
+    ]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; fail loudly if it has not been built (`__graft_entry__.build()`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise CcnetError(f"{LIB_PATH} not found: build it with `make -C {_HERE / 'csrc'}` "
+                         "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.ccnet_strerror.restype = C.c_char_p
+    lib.ccnet_strerror.argtypes = [i]
+    lib.ccnet_version.restype = i
+    lib.ccnet_arch.restype = C.c_char_p
+    lib.ccnet_conv_gemm_bf16.argtypes = [C.POINTER(ConvParams), vp]
+    lib.ccnet_conv_in_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, vp, i, i, vp, i, i, i, vp]
+    lib.ccnet_conv_out_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, vp, vp]
+    lib.ccnet_groupnorm_workspace_bytes.restype = sz
+    lib.ccnet_groupnorm_workspace_bytes.argtypes = [i, i, i, i]
+    lib.ccnet_groupnorm_bf16.argtypes = [vp, i, i, vp, i, i, i, i, i, f, vp, vp, i, vp, i, vp, sz, vp]
+    lib.ccnet_layernorm_bf16.argtypes = [vp, i, i, i, f, vp, vp, vp, i, vp]
+    lib.ccnet_geglu_bf16.argtypes = [vp, i, i, i, vp, i, vp]
+    lib.ccnet_attention_d64_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, vp]
+    lib.ccnet_softmax_rows_bf16.argtypes = [vp, i, i, i, f, vp, i, vp]
+    lib.ccnet_timestep_embedding.argtypes = [vp, i, i, i, vp, vp, vp]
+    lib.ccnet_linear_f32.argtypes = [vp, i, i, i, vp, vp, i, i, i, vp, i, vp, i, vp]
+    lib.ccnet_cfg_scheduler_step.argtypes = [vp, i, f, vp, vp, vp, vp, i, i, vp]
+    lib.ccnet_nchw_f32_to_nhwc_bf16.argtypes = [vp, i, i, i, vp, i, vp]
+    lib.ccnet_nhwc_bf16_to_nchw_f32.argtypes = [vp, i, i, i, i, vp, vp]
+    lib.ccnet_to_uint8.argtypes = [vp, i, i, i, vp, vp]
+    lib.ccnet_prof_enable.argtypes = [i]
+    lib.ccnet_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:  # default
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise CcnetError(f"{what}: {load().ccnet_strerror(rc).decode()} (code {rc})")

@@ -1,0 +1,270 @@
+"""Tensor-level wrappers over the C ABI (include/ccnet_hip.h).
+
+PyTorch is used only as the owner of device memory and of the HIP stream; every op below enqueues one or two
+hand-written gfx950 kernels on `torch.cuda.current_stream()`.  Activations travel as `Act`: a 2-D bf16
+tensor [N*H*W, C] (NHWC, "pixel rows") plus its geometry.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _l
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class Act:
+    t: torch.Tensor  # [N*H*W, ld] bf16, row stride t.stride(0)
+    N: int
+    H: int
+    W: int
+    C: int
+
+    @property
+    def ld(self) -> int:
+        return self.t.stride(0)
+
+    @property
+    def rows(self) -> int:
+        return self.N * self.H * self.W
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _l.CcnetError("ccnet_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+
+
+def new_act(N, H, W, Cch, device) -> Act:
+    return Act(torch.empty((N * H * W, Cch), dtype=BF16, device=device), N, H, W, Cch)
+
+
+def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: int = 3, stride: int = 1,
+         pad: Optional[int] = None, ups: int = 1, x2: Optional[Act] = None, rowvec: Optional[torch.Tensor] = None,
+         res1: Optional[Act] = None, scale: float = 1.0, act: int = 0, res2: Optional[Act] = None,
+         out_hw: Optional[Tuple[int, int]] = None, out: Optional[Act] = None):
+    """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given."""
+    lib = _l.load()
+    _need_cuda(x.t, w)
+    if pad is None:
+        pad = R // 2
+    Hl, Wl = x.H * ups, x.W * ups
+    if out_hw is None:
+        Ho = (Hl + 2 * pad - R) // stride + 1
+        Wo = (Wl + 2 * pad - R) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    if out is None:
+        out = new_act(x.N, Ho, Wo, Cout, x.t.device)
+    out2 = new_act(x.N, Ho, Wo, Cout, x.t.device) if res2 is not None else None
+    p = _l.ConvParams()
+    p.x1 = x.t.data_ptr(); p.x2 = _ptr(x2.t) if x2 is not None else None
+    p.w = w.data_ptr(); p.bias = _ptr(bias); p.rowvec = _ptr(rowvec)
+    p.res1 = _ptr(res1.t) if res1 is not None else None
+    p.res2 = _ptr(res2.t) if res2 is not None else None
+    p.out = out.t.data_ptr(); p.out2 = _ptr(out2.t) if out2 is not None else None
+    p.N, p.Hin, p.Win, p.Hout, p.Wout = x.N, x.H, x.W, Ho, Wo
+    p.C1 = x.C; p.C2 = x2.C if x2 is not None else 0
+    p.Cout = Cout; p.R = R; p.stride = stride; p.pad = pad; p.ups = ups
+    p.ldx1 = x.ld; p.ldx2 = x2.ld if x2 is not None else 0
+    p.ldw = w.stride(0); p.ldo = out.ld; p.ldo2 = out2.ld if out2 is not None else 0
+    p.ldres1 = res1.ld if res1 is not None else 0
+    p.ldres2 = res2.ld if res2 is not None else 0
+    p.ld_rowvec = rowvec.stride(0) if rowvec is not None else 0
+    p.act = act; p.scale = scale; p.batch = 1
+    if w.shape[1] != R * R * (p.C1 + p.C2):
+        raise _l.CcnetError(f"weight K {w.shape[1]} != R*R*(C1+C2) = {R * R * (p.C1 + p.C2)}")
+    if res1 is not None and res1.rows != out.rows:
+        raise _l.CcnetError("res1 rows mismatch")
+    if rowvec is not None and (rowvec.shape[0] != x.N or rowvec.shape[1] < Cout or rowvec.dtype != torch.float32):
+        raise _l.CcnetError("rowvec must be fp32 [N, >=Cout]")
+    _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "conv_gemm")
+    return (out, out2) if out2 is not None else out
+
+
+def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, batch: int,
+                 ldx: int, ldw: int, ldo: int, sx: int, sw: int, so: int):
+    """out[z][m][n] = sum_k x[z][m][k] * w[z][n][k] (bf16, K % 64 == 0) -- attention fallback for head dim != 64."""
+    lib = _l.load()
+    p = _l.ConvParams()
+    p.x1 = x.data_ptr(); p.w = w.data_ptr(); p.out = out.data_ptr()
+    p.N, p.Hin, p.Win, p.Hout, p.Wout = 1, M, 1, M, 1
+    p.C1 = K; p.C2 = 0; p.Cout = Nn; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
+    p.ldx1 = ldx; p.ldw = ldw; p.ldo = ldo; p.scale = 1.0; p.batch = batch
+    p.sx1 = sx; p.sw = sw; p.so = so
+    _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "gemm_batched")
+
+
+def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, Cin: int,
+           res1: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+    """Row-matrix convenience over conv(): x2d [rows, >=Cin] bf16 -> [rows, Cout]."""
+    rows = x2d.shape[0]
+    xa = Act(x2d, 1, rows, 1, Cin)
+    ra = Act(res1, 1, rows, 1, Cout) if res1 is not None else None
+    return conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale).t
+
+
+def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+              x2: Optional[Act] = None) -> Act:
+    lib = _l.load()
+    _need_cuda(x.t)
+    Cc = x.C + (x2.C if x2 is not None else 0)
+    out = new_act(x.N, x.H, x.W, Cc, x.t.device)
+    hw = x.H * x.W
+    wsb = lib.ccnet_groupnorm_workspace_bytes(x.N, hw, Cc, groups)
+    ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=x.t.device)
+    _l.check(lib.ccnet_groupnorm_bf16(x.t.data_ptr(), x.ld, x.C, _ptr(x2.t) if x2 is not None else None,
+                                      x2.ld if x2 is not None else 0, x2.C if x2 is not None else 0, x.N, hw, groups,
+                                      eps, gamma.data_ptr(), beta.data_ptr(), int(silu), out.t.data_ptr(), out.ld,
+                                      ws.data_ptr(), ws.numel() * 4, _stream()), "groupnorm")
+    return out
+
+
+def layernorm(x2d: torch.Tensor, Cc: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = _l.load()
+    _need_cuda(x2d)
+    out = torch.empty((x2d.shape[0], Cc), dtype=BF16, device=x2d.device)
+    _l.check(lib.ccnet_layernorm_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], Cc, eps, gamma.data_ptr(),
+                                      beta.data_ptr(), out.data_ptr(), out.stride(0), _stream()), "layernorm")
+    return out
+
+
+def geglu(x2d: torch.Tensor, Cc: int) -> torch.Tensor:
+    lib = _l.load()
+    out = torch.empty((x2d.shape[0], Cc), dtype=BF16, device=x2d.device)
+    _l.check(lib.ccnet_geglu_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], Cc, out.data_ptr(), out.stride(0),
+                                  _stream()), "geglu")
+    return out
+
+
+def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
+                  scale: float) -> torch.Tensor:
+    """q [B*Sq, >=H*64] (views allowed), k/v [B*Skv, >=H*64] -> o [B*Sq, H*64]."""
+    lib = _l.load()
+    _need_cuda(q, k, v)
+    o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
+    _l.check(lib.ccnet_attention_d64_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                          v.stride(0), o.data_ptr(), o.stride(0), B, H, Sq, Skv, scale, _stream()),
+             "attention_d64")
+    return o
+
+
+def softmax_rows(x2d: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
+    lib = _l.load()
+    out = torch.empty_like(x2d)
+    _l.check(lib.ccnet_softmax_rows_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], cols, scale, out.data_ptr(),
+                                         out.stride(0), _stream()), "softmax_rows")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, B: int, dim: int, freqs: torch.Tensor) -> torch.Tensor:
+    lib = _l.load()
+    _need_cuda(t, freqs)
+    out = torch.empty((B, dim), dtype=torch.float32, device=t.device)
+    _l.check(lib.ccnet_timestep_embedding(t.data_ptr(), t.numel(), B, dim, freqs.data_ptr(), out.data_ptr(),
+                                          _stream()), "timestep_embedding")
+    return out
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], silu_in: bool = False,
+               silu_out: bool = False, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _l.load()
+    _need_cuda(x, w)
+    B, K = x.shape
+    Nout = w.shape[0]
+    out = torch.empty((B, Nout), dtype=torch.float32, device=x.device)
+    _l.check(lib.ccnet_linear_f32(x.data_ptr(), x.stride(0), B, K, w.data_ptr(), _ptr(bias), Nout, int(silu_in),
+                                  int(silu_out), _ptr(add), add.stride(0) if add is not None else 0, out.data_ptr(),
+                                  out.stride(0), _stream()), "linear_f32")
+    return out
+
+
+def conv_in_small(x: torch.Tensor, N: int, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ldo: int,
+                  stride: int = 1, act: int = 0, res: Optional[Act] = None) -> Act:
+    """x fp32 NCHW [Nsrc, Cin<=8, H, W]; image n of the N outputs reads x[n % Nsrc]."""
+    lib = _l.load()
+    _need_cuda(x, w)
+    Nsrc, Cin, H, W = x.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    out = new_act(N, Ho, Wo, ldo, x.device)
+    out.C = ldo
+    _l.check(lib.ccnet_conv_in_small(x.data_ptr(), Nsrc, N, Cin, H, W, w.data_ptr(), _ptr(bias), Cout, stride, act,
+                                     _ptr(res.t) if res is not None else None, res.N if res is not None else 0,
+                                     res.ld if res is not None else 0, out.t.data_ptr(), out.ld, Ho, Wo, _stream()),
+             "conv_in_small")
+    return out
+
+
+def conv_out_small(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int) -> torch.Tensor:
+    lib = _l.load()
+    out = torch.empty((x.N, Cout, x.H, x.W), dtype=torch.float32, device=x.t.device)
+    _l.check(lib.ccnet_conv_out_small(x.t.data_ptr(), x.ld, x.N, x.H, x.W, x.C, w.data_ptr(), _ptr(bias), Cout,
+                                      out.data_ptr(), _stream()), "conv_out_small")
+    return out
+
+
+def cfg_scheduler_step(model_out: torch.Tensor, cfg_mode: int, guidance: float, coef: torch.Tensor,
+                       sample: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                       x0_out: Optional[torch.Tensor] = None) -> None:
+    """In-place update of `sample` (fp32, [B, ...]); model_out fp32 [2B or B, ...]."""
+    lib = _l.load()
+    _need_cuda(model_out, coef, sample)
+    B = sample.shape[0]
+    per = sample.numel() // B
+    _l.check(lib.ccnet_cfg_scheduler_step(model_out.data_ptr(), cfg_mode, float(guidance), coef.data_ptr(),
+                                          _ptr(noise), sample.data_ptr(), _ptr(x0_out), B, per, _stream()),
+             "cfg_scheduler_step")
+
+
+def nchw_to_act(x: torch.Tensor, ldo: Optional[int] = None) -> Act:
+    lib = _l.load()
+    _need_cuda(x)
+    N, Cc, H, W = x.shape
+    ldo = ldo or Cc
+    x = x.contiguous().float()
+    out = new_act(N, H, W, ldo, x.device)
+    _l.check(lib.ccnet_nchw_f32_to_nhwc_bf16(x.data_ptr(), N, Cc, H * W, out.t.data_ptr(), out.ld, _stream()),
+             "nchw_to_nhwc")
+    return out
+
+
+def act_to_nchw(a: Act, Cc: Optional[int] = None) -> torch.Tensor:
+    lib = _l.load()
+    Cc = Cc or a.C
+    out = torch.empty((a.N, Cc, a.H, a.W), dtype=torch.float32, device=a.t.device)
+    _l.check(lib.ccnet_nhwc_bf16_to_nchw_f32(a.t.data_ptr(), a.ld, a.N, Cc, a.H * a.W, out.data_ptr(), _stream()),
+             "nhwc_to_nchw")
+    return out
+
+
+def to_uint8(x: torch.Tensor) -> torch.Tensor:
+    lib = _l.load()
+    _need_cuda(x)
+    N, Cc, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty((N, H, W), dtype=torch.uint8, device=x.device)
+    _l.check(lib.ccnet_to_uint8(x.data_ptr(), N, Cc, H * W, out.data_ptr(), _stream()), "to_uint8")
+    return out
+
+
+def prof_enable(on: bool) -> None:
+    _l.load().ccnet_prof_enable(int(on))
+
+
+def prof_collect():
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+    _l.check(_l.load().ccnet_prof_collect(C.byref(ms), C.byref(fl), C.byref(n)), "prof_collect")
+    return ms.value, fl.value, n.value

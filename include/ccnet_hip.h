@@ -1,0 +1,161 @@
+/* ccnet_hip.h -- C ABI of libccnet_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (RichardObi/ccnet) is pure Python: it has NO native/FFI boundary.
+ * Its hot path calls third-party torch modules (monai-generative / diffusers) from
+ *   src/python/training/run_controlnet_inference.py:216-256 and
+ *   src/python/training/util.py:934-962, 1043-1092.
+ * This header is the boundary the build defines *beneath* those module calls
+ * (SURVEY.md section 8(b)): every entry point cites the reference call (or the upstream
+ * op sequence reached from it) that it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless a comment says "host";
+ *   - activations are NHWC bf16 ("pixel rows" x channels), row stride given in elements;
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*), never
+ *     synchronises, never allocates, and returns 0 or a negative CCNET_E* code
+ *     (text via ccnet_strerror); nothing throws across the boundary;
+ *   - the caller owns all memory, including workspaces (size queries provided).
+ */
+#ifndef CCNET_HIP_H
+#define CCNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCNET_OK 0
+#define CCNET_EINVAL (-1)   /* bad shape / alignment / null pointer          */
+#define CCNET_EUNSUP (-2)   /* configuration the kernels do not cover        */
+#define CCNET_ELAUNCH (-3)  /* hipLaunch failed (see hipGetLastError)        */
+#define CCNET_EWS (-4)      /* workspace too small                           */
+
+const char* ccnet_strerror(int code);
+int ccnet_version(void);          /* ABI version, bumped on any struct change */
+const char* ccnet_arch(void);     /* "gfx950" */
+
+/* ------------------------------------------------------------------ K1/K2/K8/K10
+ * Implicit-GEMM convolution / linear layer on bf16 MFMA (v_mfma_f32_32x32x16_bf16).
+ *   out[m][n] = scale * act( sum_k im2col(x)[m][k] * w[n][k] + bias[n] + rowvec[img(m)][n] ) + res1[m][n]
+ *   out2[m][n] = (same value before bf16 rounding) + res2[m][n]           (optional)
+ * Replaces: monai Convolution(conv_only)=nn.Conv2d 3x3/1x1 in ResnetBlock / Downsample /
+ * Upsample / SpatialTransformer.proj_in,proj_out; nn.Linear in CrossAttention.to_q/k/v/to_out and
+ * MLPBlock.linear1/linear2; ControlNet zero-convs with `* conditioning_scale`; the UNet's
+ * `res + additional_residual` (res2/out2) and `torch.cat([h, skip], 1)` (x1/x2) -- all reached from
+ * util.py:944 (ControlNet.forward) and util.py:1062 (DiffusionModelUNet.forward).
+ * F.interpolate(scale_factor=2,"nearest") before a conv is folded into the gather (ups=2).
+ */
+typedef struct ccnet_conv_params {
+    const void* x1;       /* bf16 [N*Hin*Win][ldx1]                                             */
+    const void* x2;       /* bf16 second source for channel concat, or NULL                     */
+    const void* w;        /* bf16 [Cout][ldw], K order = (kr, ks, c over x1 then x2)            */
+    const float* bias;    /* [Cout] or NULL                                                     */
+    const float* rowvec;  /* [N][ld_rowvec] per-image additive vector (time-embedding) or NULL  */
+    const void* res1;     /* bf16 [M][ldres1] or NULL                                           */
+    const void* res2;     /* bf16 [M][ldres2] or NULL (requires out2)                           */
+    void* out;            /* bf16 [M][ldo]                                                      */
+    void* out2;           /* bf16 [M][ldo2] or NULL                                             */
+    int32_t N, Hin, Win;  /* input images and their (pre-upsample) size                         */
+    int32_t Hout, Wout;   /* output size; M = N*Hout*Wout                                       */
+    int32_t C1, C2;       /* channels taken from x1 / x2 (multiples of 64; C2 = 0 if no x2)     */
+    int32_t Cout;         /* multiple of 8                                                      */
+    int32_t R;            /* kernel size, 1 or 3 (square)                                       */
+    int32_t stride, pad;  /* pad_lo; the high side is implied by Hout/Wout                      */
+    int32_t ups;          /* 1, or 2 = nearest-neighbour x2 upsample folded into the gather     */
+    int32_t ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec;  /* row strides in elements  */
+    int32_t act;          /* 0 none, 1 SiLU                                                     */
+    float scale;
+    int32_t batch;        /* >1: batched plain GEMM (R==1); z-th problem uses the strides below */
+    int64_t sx1, sw, so;  /* element strides between batch problems for x1, w, out              */
+    int32_t reserved[4];
+} ccnet_conv_params;
+
+int ccnet_conv_gemm_bf16(const ccnet_conv_params* p /*host*/, void* stream);
+
+/* Direct 3x3 convolution for tiny channel counts at the network edges.
+ *   conv_in_small : x fp32 NCHW [Nsrc][Cin<=8][H][W] (image n reads x[n % Nsrc]) -> NHWC bf16 [N][Hout][Wout][ldo]
+ *                   out = act(conv(x) + bias) + res[n % Nres]   (res NHWC bf16, optional)
+ *   conv_out_small: x NHWC bf16 -> fp32 NCHW [N][Cout<=8][H][W], stride 1, pad 1
+ * Replaces: conv_in (4->C0), controlnet_cond_embedding.conv_in (1->e0) and `h = conv_in(x) + cond_emb`,
+ * the UNet `out.2` conv (C0->4) and the AEKL decoder's last conv (util.py:944,1062; run_controlnet_inference.py:256).
+ */
+int ccnet_conv_in_small(const float* x, int Nsrc, int N, int Cin, int H, int W,
+                        const float* w /*[Cout][Cin][3][3] fp32*/, const float* bias, int Cout,
+                        int stride, int act, const void* res, int Nres, int ldres,
+                        void* out, int ldo, int Hout, int Wout, void* stream);
+int ccnet_conv_out_small(const void* x, int ldx, int N, int H, int W, int Cin,
+                         const void* w /*bf16 [Cout][9][Cin]*/, const float* bias, int Cout,
+                         float* out, void* stream);
+
+/* ------------------------------------------------------------------ K3
+ * GroupNorm (+ optional SiLU) over NHWC bf16, fp32 statistics, optional two-source channel concat.
+ * Replaces nn.GroupNorm(32,C,eps)+F.silu in ResnetBlock.norm1/norm2, `out.0/1`, SpatialTransformer.norm,
+ * AEKL ResBlock norms; with x2 != NULL also the torch.cat before norm1 of every up-block ResnetBlock.
+ * Two launches inside: partial (sum, sumsq) per (image, pixel-chunk, group) -> apply.
+ */
+size_t ccnet_groupnorm_workspace_bytes(int N, int HW, int C, int groups);
+int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2,
+                         int N, int HW, int groups, float eps, const float* gamma, const float* beta,
+                         int silu, void* out, int ldo, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K6: nn.LayerNorm(C, eps) over rows of a [rows][ldx] bf16 matrix (BasicTransformerBlock.norm1/2/3). */
+int ccnet_layernorm_bf16(const void* x, int ldx, int rows, int C, float eps, const float* gamma,
+                         const float* beta, void* out, int ldo, void* stream);
+
+/* K7: GEGLU, out[r][c] = a[r][c] * gelu_erf(g[r][c]) with a = x[:, :C], g = x[:, C:2C] (MLPBlock act="GEGLU"). */
+int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo, void* stream);
+
+/* ------------------------------------------------------------------ K4/K5
+ * Flash-style attention, head dim 64, bf16 in/out, fp32 online softmax.
+ *   O[b, i, h*64:(h+1)*64] = softmax_j( scale * Q[b,i,h] . K[b,j,h] ) V[b,j,h]
+ * Q rows: b*Sq + i, K/V rows: b*Skv + j; ld* are row strides in elements, head h at column h*64.
+ * Replaces CrossAttention._attention (baddbmm -> softmax -> bmm) for self (context = x) and
+ * 77-token cross attention (context = prompt_embeds).
+ */
+int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                             void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream);
+
+/* Row softmax (in place capable), bf16 rows of length `cols` scaled by `scale` before exp; used by the
+ * generic-head-dim attention fallback (single head of 512/768 channels in the repo's YAML geometry). */
+int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, float scale, void* out, int ldo, void* stream);
+
+/* ------------------------------------------------------------------ K11
+ * fp32 embedding path. timestep_embedding: emb[b][0:half]=cos(t_b*freqs), [half:dim]=sin (cos first);
+ * freqs = exp(-ln(10000)*arange(half)/half) is computed once on the host in fp32.
+ * linear_f32: y[b][n] = act_out( sum_k act_in(x[b][k]) * w[n][k] + bias[n] ) + add[b][n]
+ * (time_embed, CCnet class_embedding MLP util.py:1128-1132, all time_emb_proj(silu(emb)) rows at once).
+ */
+int ccnet_timestep_embedding(const float* t /*[nt]*/, int nt, int B, int dim, const float* freqs /*[dim/2]*/,
+                             float* out, void* stream);
+int ccnet_linear_f32(const float* x, int ldx, int B, int K, const float* w, const float* bias, int Nout,
+                     int silu_in, int silu_out, const float* add, int ldadd, float* out, int ldo, void* stream);
+
+/* ------------------------------------------------------------------ K9
+ * Classifier-free-guidance combine + scheduler step, fp32, one launch.
+ *   model_out fp32 NCHW [2B or B][...]: uncond = first B images, text = last B (run_controlnet_inference.py:245).
+ *   mode 0: pred=text (guidance None), 1: pred=uncond (guidance 0), 2: uncond + g*(text-uncond).
+ *   coef (device, 8 floats): {sqrt_acp_t, sqrt_1m_acp_t, c_x0, c_eps_or_xt, sigma, clip(0/1), pred_type(0 eps,1 sample,2 v), ddpm(0/1)}
+ *   DDIM: prev = c_x0*x0 + c_eps*eps ; DDPM: prev = c_x0*x0 + c_xt*x + sigma*noise   (scheduler.step, :253)
+ */
+int ccnet_cfg_scheduler_step(const float* model_out, int cfg_mode, float guidance, const float* coef,
+                             const float* noise /*or NULL*/, float* sample /*in/out*/, float* x0_out /*or NULL*/,
+                             int B, int per_image, void* stream);
+
+/* fp32 NCHW <-> bf16 NHWC helpers for the module-level API (ControlNet residual lists are NCHW tensors). */
+int ccnet_nchw_f32_to_nhwc_bf16(const float* x, int N, int C, int HW, void* out, int ldo, void* stream);
+int ccnet_nhwc_bf16_to_nchw_f32(const void* x, int ldx, int N, int C, int HW, float* out, void* stream);
+
+/* clip((x+1)/2,0,1) -> rint(*255) -> uint8 of channel 0 (util.py:1162-1173,1412-1416). x fp32 NCHW. */
+int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------ profiling hooks for bench.py
+ * When enabled, ccnet_conv_gemm_bf16 brackets each launch with hipEvents on `stream`;
+ * ccnet_prof_collect synchronises the events and returns summed kernel ms / FLOPs / launches. */
+int ccnet_prof_enable(int on);
+int ccnet_prof_collect(double* ms, double* flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

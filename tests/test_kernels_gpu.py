@@ -1,0 +1,280 @@
+"""Per-kernel parity: every HIP kernel, called through the C ABI, against the same op in plain PyTorch fp32
+on the same (bf16-rounded) inputs.  Tolerances are bf16-output tolerances: |err| <= atol + rtol*|ref| with
+rtol = 2^-7 (one bf16 ulp is 2^-8 relative) unless a test states otherwise.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2.0 ** -7
+
+
+def _ops():
+    from ccnet_amd import ops
+    return ops
+
+
+def _rand_act(N, H, W, C, dev, seed, scale=1.0):
+    from ccnet_amd.ops import Act
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = (torch.randn(N * H * W, C, generator=g) * scale).to(torch.bfloat16).to(dev)
+    return Act(t, N, H, W, C)
+
+
+def _nchw(a, C=None):
+    C = C or a.C
+    return a.t[:, :C].float().reshape(a.N, a.H, a.W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def _close(out, ref, atol, rtol=RTOL, what=""):
+    err = (out - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = (err > bound)
+    assert not bad.any(), f"{what}: max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g}), " \
+                          f"{bad.sum().item()} / {bad.numel()} outside tolerance"
+
+
+def _pack_w(w):  # [Cout, Cin, R, R] fp32 -> bf16 [Cout, R*R*Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(torch.bfloat16)
+
+
+CONV_CASES = [
+    # N, H, W, C1, C2, Cout, R, stride, ups
+    (2, 16, 16, 64, 0, 128, 3, 1, 1),
+    (2, 16, 16, 128, 0, 320, 3, 1, 1),
+    (1, 7, 9, 64, 0, 72, 3, 1, 1),       # ragged M and a partial cout tile
+    (2, 16, 16, 64, 0, 64, 3, 2, 1),     # stride 2
+    (2, 8, 8, 64, 0, 64, 3, 1, 2),       # nearest x2 upsample folded into the gather
+    (2, 8, 8, 128, 64, 128, 3, 1, 1),    # channel concat of two sources
+    (2, 8, 8, 64, 128, 64, 1, 1, 1),     # 1x1 over a concat
+    (4, 32, 32, 320, 0, 320, 3, 1, 1),   # G1 level-0 shape at reduced size -> 128x128 / 128x64 tiles
+    (32, 8, 8, 1280, 0, 1280, 1, 1, 1),
+    (3, 5, 5, 64, 0, 8, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_gemm(cuda, case):
+    ops = _ops()
+    N, H, W, C1, C2, Cout, R, stride, ups = case
+    x1 = _rand_act(N, H, W, C1, cuda, 1)
+    x2 = _rand_act(N, H, W, C2, cuda, 2) if C2 else None
+    g = torch.Generator().manual_seed(3)
+    Cin = C1 + C2
+    w = torch.randn(Cout, Cin, R, R, generator=g) / math.sqrt(Cin * R * R)
+    b = torch.randn(Cout, generator=g)
+    wp = _pack_w(w).to(cuda)
+    out = ops.conv(x1, wp, b.to(cuda), Cout, R=R, stride=stride, ups=ups, x2=x2)
+    xin = _nchw(x1) if x2 is None else torch.cat([_nchw(x1), _nchw(x2)], 1)
+    if ups == 2:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wp.float().reshape(Cout, R, R, Cin).permute(0, 3, 1, 2).to(cuda), b.to(cuda), stride=stride,
+                   padding=R // 2)
+    assert (out.H, out.W) == tuple(ref.shape[2:])
+    _close(_nchw(out), ref, atol=2e-2, what=f"conv {case}")
+
+
+def test_conv_epilogue_full(cuda):
+    """bias + per-image rowvec + SiLU + scale + residual + dual output in one launch."""
+    ops = _ops()
+    N, H, W, C, Cout = 3, 8, 8, 128, 192
+    x = _rand_act(N, H, W, C, cuda, 5)
+    r1 = _rand_act(N, H, W, Cout, cuda, 6)
+    r2 = _rand_act(N, H, W, Cout, cuda, 7)
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(N, Cout, generator=g).to(cuda)
+    wp = _pack_w(w).to(cuda)
+    out, out2 = ops.conv(x, wp, b.to(cuda), Cout, R=3, rowvec=rv, act=1, scale=0.7, res1=r1, res2=r2)
+    ref = F.conv2d(_nchw(x), wp.float().reshape(Cout, 3, 3, C).permute(0, 3, 1, 2), b.to(cuda), padding=1)
+    ref = F.silu(ref + rv[:, :, None, None]) * 0.7 + _nchw(r1)
+    _close(_nchw(out), ref, atol=2e-2, what="epilogue out")
+    _close(_nchw(out2), ref + _nchw(r2), atol=3e-2, what="epilogue out2")
+
+
+def test_gemm_batched(cuda):
+    ops = _ops()
+    Bt, M, Nn, K = 3, 100, 72, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(Bt, M, K, generator=g).to(torch.bfloat16).to(cuda)
+    w = torch.randn(Bt, Nn, K, generator=g).to(torch.bfloat16).to(cuda)
+    out = torch.empty(Bt, M, Nn, dtype=torch.bfloat16, device=cuda)
+    ops.gemm_batched(x, w, out, M, Nn, K, Bt, K, K, Nn, M * K, Nn * K, M * Nn)
+    ref = torch.bmm(x.float(), w.float().transpose(1, 2))
+    _close(out.float(), ref, atol=0.15, what="batched gemm")
+
+
+GN_CASES = [(2, 16, 16, 320, 0), (2, 8, 8, 1280, 1280), (1, 7, 7, 256, 0), (2, 32, 32, 128, 0), (3, 4, 4, 640, 320),
+            (2, 64, 64, 320, 0)]
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm(cuda, case, silu):
+    ops = _ops()
+    N, H, W, C1, C2 = case
+    x1 = _rand_act(N, H, W, C1, cuda, 21, scale=2.0)
+    x1.t += 0.5
+    x2 = _rand_act(N, H, W, C2, cuda, 22) if C2 else None
+    C = C1 + C2
+    g = torch.Generator().manual_seed(23)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(C, generator=g)).to(cuda)
+    out = ops.groupnorm(x1, gamma, beta, 32, 1e-5, silu, x2=x2)
+    xin = _nchw(x1) if x2 is None else torch.cat([_nchw(x1), _nchw(x2)], 1)
+    ref = F.group_norm(xin, 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    _close(_nchw(out), ref, atol=1e-2, what=f"groupnorm {case}")
+
+
+@pytest.mark.parametrize("rows,C", [(100, 320), (64, 640), (33, 1280), (10, 512), (7, 768)])
+def test_layernorm(cuda, rows, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16).to(cuda)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(C, generator=g)).to(cuda)
+    out = ops.layernorm(x, C, gamma, beta, 1e-5)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    _close(out.float(), ref, atol=1e-2, what="layernorm")
+
+
+def test_geglu(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(50, 2 * 1280, generator=g) * 2).to(torch.bfloat16).to(cuda)
+    out = ops.geglu(x, 1280)
+    a, gg = x.float().chunk(2, dim=-1)
+    _close(out.float(), a * F.gelu(gg), atol=1e-2, what="geglu")
+
+
+ATT_CASES = [(2, 5, 256, 256), (1, 10, 1024, 1024), (2, 20, 64, 77), (1, 5, 4096, 4096), (2, 3, 49, 49),
+             (1, 2, 784, 77), (3, 1, 200, 130)]
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attention_d64(cuda, case):
+    ops = _ops()
+    B, H, Sq, Skv = case
+    g = torch.Generator().manual_seed(51)
+    # fused-QKV style views: q/k/v are column slices of wider row matrices
+    qkv = torch.randn(B * Sq, 3 * H * 64, generator=g).to(torch.bfloat16).to(cuda)
+    kv = torch.randn(B * Skv, 2 * H * 64, generator=g).to(torch.bfloat16).to(cuda)
+    q = qkv[:, : H * 64]
+    k, v = kv[:, : H * 64], kv[:, H * 64:]
+    scale = 1.0 / 8.0
+    o = ops.attention_d64(q, k, v, B, H, Sq, Skv, scale)
+    qf = q.float().reshape(B, Sq, H, 64).permute(0, 2, 1, 3)
+    kf = k.float().reshape(B, Skv, H, 64).permute(0, 2, 1, 3)
+    vf = v.float().reshape(B, Skv, H, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(qf @ kf.transpose(-1, -2) * scale, dim=-1)
+    ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * Sq, H * 64)
+    _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attention {case}")
+
+
+def test_attention_rescale_branch(cuda):
+    """Online-softmax rescale: a key in a LATE tile dominates, so the running max jumps after O has mass."""
+    ops = _ops()
+    B, H, Sq, Skv = 1, 1, 64, 256
+    g = torch.Generator().manual_seed(52)
+    q = torch.randn(Sq, 64, generator=g)
+    k = torch.randn(Skv, 64, generator=g) * 0.1
+    v = torch.randn(Skv, 64, generator=g)
+    k[200] = q[3] * 4.0  # spike for query 3 in the 4th key tile
+    k[70] = q[40] * 3.0
+    qb, kb, vb = (t.to(torch.bfloat16).to(cuda) for t in (q, k, v))
+    o = ops.attention_d64(qb, kb, vb, B, H, Sq, Skv, 0.125)
+    p = torch.softmax(qb.float() @ kb.float().T * 0.125, dim=-1)
+    ref = p @ vb.float()
+    _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what="attention rescale")
+
+
+def test_softmax_rows(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(53)
+    x = (torch.randn(37, 196, generator=g) * 3).to(torch.bfloat16).to(cuda)
+    out = ops.softmax_rows(x, 196, 0.5)
+    _close(out.float(), torch.softmax(x.float() * 0.5, -1), atol=2e-3, what="softmax rows")
+
+
+def test_timestep_embedding_and_linear(cuda):
+    ops = _ops()
+    dim, B = 320, 6
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    t = torch.tensor([980.0], device=cuda)
+    emb = ops.timestep_embedding(t, B, dim, freqs.to(cuda))
+    args = torch.tensor([980.0])[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1).expand(B, -1)
+    assert (emb.cpu() - ref).abs().max() < 2e-4
+    g = torch.Generator().manual_seed(61)
+    w = torch.randn(1280, dim, generator=g) / math.sqrt(dim)
+    b = torch.randn(1280, generator=g)
+    add = torch.randn(B, 1280, generator=g)
+    y = ops.linear_f32(emb, w.to(cuda), b.to(cuda), silu_in=True, silu_out=True, add=add.to(cuda))
+    yref = F.silu(F.linear(F.silu(emb.cpu()), w, b)) + add
+    assert (y.cpu() - yref).abs().max() < 1e-4
+
+
+def test_small_convs(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(71)
+    # conv_in: 4 -> 320 with CFG-style source duplication and an added NHWC residual
+    x = torch.randn(2, 4, 16, 16, generator=g).to(cuda)
+    w = torch.randn(320, 4, 3, 3, generator=g) / 6
+    b = torch.randn(320, generator=g)
+    res = _rand_act(2, 16, 16, 320, cuda, 72)
+    out = ops.conv_in_small(x, 4, w.to(cuda), b.to(cuda), 320, 320, res=res)
+    ref = F.conv2d(torch.cat([x, x]), w.to(cuda), b.to(cuda), padding=1) + torch.cat([_nchw(res), _nchw(res)])
+    _close(_nchw(out), ref, atol=2e-2, what="conv_in_small")
+    # 1 -> 16 (padded to 64 channels), SiLU, stride 1; padded channels must be exactly zero
+    c = torch.randn(2, 1, 32, 32, generator=g).to(cuda)
+    w1 = torch.randn(16, 1, 3, 3, generator=g) / 3
+    b1 = torch.randn(16, generator=g)
+    o1 = ops.conv_in_small(c, 2, w1.to(cuda), b1.to(cuda), 16, 64, act=1)
+    _close(_nchw(o1, 16), F.silu(F.conv2d(c, w1.to(cuda), b1.to(cuda), padding=1)), atol=1e-2, what="cond conv_in")
+    assert o1.t[:, 16:].abs().max().item() == 0.0
+    # conv_out: 320 -> 4 to fp32 NCHW
+    xa = _rand_act(2, 16, 16, 320, cuda, 73)
+    wo = (torch.randn(4, 320, 3, 3, generator=g) / math.sqrt(2880))
+    bo = torch.randn(4, generator=g)
+    wop = wo.permute(0, 2, 3, 1).reshape(4, 9, 320).contiguous().to(torch.bfloat16).to(cuda)
+    y = ops.conv_out_small(xa, wop, bo.to(cuda), 4)
+    yref = F.conv2d(_nchw(xa), wop.float().reshape(4, 3, 3, 320).permute(0, 3, 1, 2), bo.to(cuda), padding=1)
+    assert (y - yref).abs().max() < 2e-3
+
+
+def test_cfg_scheduler_step_and_converters(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(81)
+    B = 3
+    mo = torch.randn(2 * B, 4, 8, 8, generator=g).to(cuda)
+    x = torch.randn(B, 4, 8, 8, generator=g).to(cuda)
+    a_t, a_p = 0.3, 0.45
+    coef = torch.tensor([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5, 0.0, 0.0, 2.0, 0.0], device=cuda)
+    xs = x.clone()
+    x0 = torch.empty_like(x)
+    ops.cfg_scheduler_step(mo, 2, 7.0, coef, xs, x0_out=x0)
+    u, t = mo.chunk(2)
+    v = u + 7.0 * (t - u)
+    x0r = a_t ** 0.5 * x - (1 - a_t) ** 0.5 * v
+    eps = a_t ** 0.5 * v + (1 - a_t) ** 0.5 * x
+    ref = a_p ** 0.5 * x0r + (1 - a_p) ** 0.5 * eps
+    assert (xs - ref).abs().max() < 1e-5 and (x0 - x0r).abs().max() < 1e-5
+    # layout converters + uint8 map
+    y = torch.randn(2, 70, 9, 9, generator=g).to(cuda)
+    a = ops.nchw_to_act(y, 128)
+    assert a.t[:, 70:].abs().max().item() == 0.0
+    back = ops.act_to_nchw(a, 70)
+    assert (back - y.to(torch.bfloat16).float()).abs().max().item() == 0.0
+    img = torch.randn(2, 1, 16, 16, generator=g).to(cuda)
+    u8 = ops.to_uint8(img).cpu()
+    import numpy as np
+    refu8 = np.rint(np.clip((img.cpu().numpy().astype(np.float64) + 1) / 2, 0, 1) * 255).astype(np.uint8)[:, 0]
+    assert np.abs(u8.numpy().astype(int) - refu8.astype(int)).max() <= 1  # fp32 vs fp64 rint ties
