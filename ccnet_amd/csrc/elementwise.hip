@@ -250,6 +250,35 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* x, int N, in
     }
 }
 
+// 1x1 convolution on <= 8 fp32 NCHW channels (AEKL quant / post-quant convs); mode 1 = exp(clamp(v,-30,20)/2)
+__global__ __launch_bounds__(256) void pointwise_nchw_kernel(const float* x, int N, int Cin, int HW, const float* w,
+                                                             const float* b, int Cout, int mode, float* out) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, p = i % HW;
+        float xv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[c] = c < Cin ? x[(n * Cin + c) * HW + p] : 0.f;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            if (co < Cout) {
+                float s = b ? b[co] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < Cin) s += w[co * Cin + c] * xv[c];
+                if (mode == 1) s = expf(fminf(fmaxf(s, -30.f), 20.f) * 0.5f);
+                out[(n * Cout + co) * HW + p] = s;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* a, const float* b, const float* c, long long n,
+                                                   float* out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = a[i] + b[i] * c[i];
+}
+
 int grid_for(long long total, int per_block) {
     long long g = (total + per_block - 1) / per_block;
     if (g > 4096) g = 4096;
@@ -357,6 +386,23 @@ extern "C" int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return CCNET_EINVAL;
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for((long long)N * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, N,
                        C, HW, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_pointwise_nchw_f32(const float* x, int N, int Cin, int HW, const float* w, const float* bias,
+                                        int Cout, int mode, float* out, void* stream) {
+    if (!x || !w || !out || N <= 0 || HW <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > 8 || mode < 0 || mode > 1)
+        return CCNET_EINVAL;
+    hipLaunchKernelGGL(pointwise_nchw_kernel, dim3(grid_for((long long)N * HW, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, N, Cin, HW, w, bias, Cout, mode, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_axpy_f32(const float* a, const float* b, const float* c, long long n, float* out, void* stream) {
+    if (!a || !b || !c || !out || n <= 0) return CCNET_EINVAL;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n, out);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

@@ -29,12 +29,12 @@ __device__ __forceinline__ u32x4 gn_load(const GnArgs& a, long long pixrow, int 
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
+    // per-(pixel-row-slot, channel) partials; rows_par * C <= GN_MAXC by construction.  Reduced in a fixed order
+    // (no float atomics) so the statistics, and with them the whole sampler, are bit-reproducible run to run.
     __shared__ float s_sum[GN_MAXC], s_sq[GN_MAXC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int cols = a.C / 8;
     const int p0 = chunk * a.ppc, p1 = min(a.HW, p0 + a.ppc);
-    for (int c = tid; c < a.C; c += GN_THREADS) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
     const int cstride = cols < GN_THREADS ? cols : GN_THREADS;  // columns covered per sweep
     const int rows_par = GN_THREADS / cstride;                   // pixel rows processed in parallel
     const int my_col = tid % cstride, my_row = tid / cstride;
@@ -51,15 +51,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(&s_sum[col * 8 + e], s[e]);
-                atomicAdd(&s_sq[col * 8 + e], q[e]);
+                s_sum[my_row * a.C + col * 8 + e] = s[e];
+                s_sq[my_row * a.C + col * 8 + e] = q[e];
             }
         }
     }
     __syncthreads();
     if (tid < a.groups) {
         float s = 0.f, q = 0.f;
-        for (int c = tid * a.cpg; c < (tid + 1) * a.cpg; ++c) { s += s_sum[c]; q += s_sq[c]; }
+        for (int r = 0; r < rows_par; ++r)
+            for (int c = tid * a.cpg; c < (tid + 1) * a.cpg; ++c) { s += s_sum[r * a.C + c]; q += s_sq[r * a.C + c]; }
         const float cnt = (float)((p1 - p0) * a.cpg);
         const float mean = s / cnt;
         float* w = a.ws + (((long long)n * a.chunks + chunk) * a.groups + tid) * 2;

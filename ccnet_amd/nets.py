@@ -1,0 +1,841 @@
+"""MI355X-native DiffusionModelUNet / ControlNet / AutoencoderKL with the reference's L2 call surface.
+
+Drop-in boundary:
+  * `DiffusionModelUNet(**config["ldm"]["params"])`, `.forward(x, timesteps, context, class_labels=None,
+    down_block_additional_residuals=None, mid_block_additional_residual=None)`      -- util.py:1297, 1054-1069
+  * `ControlNet(**config["controlnet"]["params"])`, `.forward(x, timesteps, controlnet_cond,
+    conditioning_scale=1.0, context=None, class_labels=None) -> (list, mid)`        -- util.py:1356, 944-951
+  * `AutoencoderKL(**config["stage1"]["params"])`, `.encode/.sampling/.decode/.forward` -- util.py:1268, 1490-1491
+  * `adjust_class_embedding(model)`                                                 -- util.py:1094-1132
+  * `.state_dict()/.load_state_dict()` with monai-generative key names; class names
+    contain "DiffusionModelUNet" / "ControlNet" (not "ControlNetModel") because the reference dispatches on
+    them (util.py:943, 1051, 1100).
+
+Architecture: the nn.Module tree below only HOLDS parameters (standard torch layers are used as containers so
+default initialisation and key names match upstream); nothing in it has a torch forward.  `forward` lowers the
+network to a sequence of hand-written gfx950 kernels (ccnet_amd.ops -> libccnet_hip.so): activations are NHWC
+bf16 resident in HBM, weights are packed once to bf16 [Cout][kr][ks][Cin], GroupNorm/softmax/embedding
+statistics stay in fp32.  There is no CPU or eager fallback: without the HIP library every forward raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import CcnetError
+from .ops import Act
+
+BF16 = torch.bfloat16
+
+
+def _tuple(v, n):
+    return tuple(v) if isinstance(v, (list, tuple)) else tuple([v] * n)
+
+
+def _pad64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _Holder(nn.Module):
+    """Parameter container; deliberately has no forward."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise CcnetError("parameter container: compute goes through the owning network's HIP lowering")
+
+
+def _zero(m: nn.Module) -> nn.Module:
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+def _convolution(cin, cout, k=3, stride=1, pad=1) -> _Holder:
+    h = _Holder()
+    h.conv = nn.Conv2d(cin, cout, k, stride, pad, bias=True)
+    return h
+
+
+def _cross_attention(query_dim, cross_dim, heads, head_ch) -> _Holder:
+    h = _Holder()
+    inner = heads * head_ch
+    cross_dim = cross_dim if cross_dim is not None else query_dim
+    h.to_q = nn.Linear(query_dim, inner, bias=False)
+    h.to_k = nn.Linear(cross_dim, inner, bias=False)
+    h.to_v = nn.Linear(cross_dim, inner, bias=False)
+    h.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+    return h
+
+
+def _transformer_block(ch, heads, head_ch, cross_dim) -> _Holder:
+    h = _Holder()
+    h.attn1 = _cross_attention(ch, None, heads, head_ch)
+    ff = _Holder()
+    ff.linear1 = nn.Linear(ch, ch * 8)
+    ff.linear2 = nn.Linear(ch * 4, ch)
+    h.ff = ff
+    h.attn2 = _cross_attention(ch, cross_dim, heads, head_ch)
+    h.norm1 = nn.LayerNorm(ch)
+    h.norm2 = nn.LayerNorm(ch)
+    h.norm3 = nn.LayerNorm(ch)
+    return h
+
+
+def _spatial_transformer(ch, heads, head_ch, layers, groups, eps, cross_dim) -> _Holder:
+    h = _Holder()
+    inner = heads * head_ch
+    h.norm = nn.GroupNorm(groups, ch, eps=eps, affine=True)
+    h.proj_in = _convolution(ch, inner, 1, 1, 0)
+    h.transformer_blocks = nn.ModuleList([_transformer_block(inner, heads, head_ch, cross_dim) for _ in range(layers)])
+    h.proj_out = _zero(_convolution(inner, ch, 1, 1, 0))
+    h.heads, h.head_ch = heads, head_ch
+    return h
+
+
+def _resnet(cin, temb, cout, groups, eps) -> _Holder:
+    h = _Holder()
+    h.norm1 = nn.GroupNorm(groups, cin, eps=eps, affine=True)
+    h.conv1 = _convolution(cin, cout)
+    h.time_emb_proj = nn.Linear(temb, cout)
+    h.norm2 = nn.GroupNorm(groups, cout, eps=eps, affine=True)
+    h.conv2 = _zero(_convolution(cout, cout))
+    h.skip_connection = nn.Identity() if cin == cout else _convolution(cin, cout, 1, 1, 0)
+    h.cin, h.cout = cin, cout
+    return h
+
+
+class _Trunk(nn.Module):
+    """conv_in + embeddings + down blocks + middle block (shared by UNet and ControlNet)."""
+
+    def _build_trunk(self, in_channels, num_res_blocks, num_channels, attention_levels, norm_num_groups, norm_eps,
+                     num_head_channels, with_conditioning, transformer_num_layers, cross_attention_dim,
+                     num_class_embeds):
+        n = len(num_channels)
+        if with_conditioning and cross_attention_dim is None:
+            raise ValueError("DiffusionModelUNet expects dimension of the cross-attention conditioning "
+                             "(cross_attention_dim) when using with_conditioning.")
+        if any(attention_levels) and not with_conditioning:
+            raise NotImplementedError("attention without conditioning is not on the ccnet hot path")
+        if any(c % norm_num_groups for c in num_channels):
+            raise ValueError("DiffusionModelUNet expects all num_channels being multiple of norm_num_groups")
+        if any(c % 64 for c in num_channels):
+            raise CcnetError("the MI355X lowering needs every entry of num_channels to be a multiple of 64")
+        if transformer_num_layers != 1:
+            raise NotImplementedError("transformer_num_layers != 1")
+        self.in_channels = in_channels
+        self.block_out_channels = list(num_channels)
+        self.num_res_blocks_ = _tuple(num_res_blocks, n)
+        self.num_head_channels_ = _tuple(num_head_channels, n)
+        self.attention_levels_ = tuple(bool(a) for a in attention_levels)
+        self.norm_num_groups, self.norm_eps = norm_num_groups, norm_eps
+        self.with_conditioning = with_conditioning
+        self.cross_attention_dim = cross_attention_dim
+        c0 = num_channels[0]
+        ted = c0 * 4
+        self.conv_in = _convolution(in_channels, c0)
+        self.time_embed = nn.Sequential(nn.Linear(c0, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.num_class_embeds = num_class_embeds
+        if num_class_embeds is not None:
+            self.class_embedding = nn.Embedding(num_class_embeds, ted)
+        self.down_blocks = nn.ModuleList()
+        out_ch = c0
+        for i in range(n):
+            in_ch, out_ch = out_ch, num_channels[i]
+            blk = _Holder()
+            blk.resnets = nn.ModuleList()
+            att = bool(attention_levels[i]) and with_conditioning
+            atts = []
+            for j in range(self.num_res_blocks_[i]):
+                blk.resnets.append(_resnet(in_ch if j == 0 else out_ch, ted, out_ch, norm_num_groups, norm_eps))
+                if att:
+                    hc = self.num_head_channels_[i]
+                    atts.append(_spatial_transformer(out_ch, out_ch // hc, hc, 1, norm_num_groups, norm_eps,
+                                                     cross_attention_dim))
+            if att:
+                blk.attentions = nn.ModuleList(atts)
+            if i != n - 1:
+                ds = _Holder()
+                ds.op = _convolution(out_ch, out_ch, 3, 2, 1)
+                blk.downsampler = ds
+            else:
+                blk.downsampler = None
+            self.down_blocks.append(blk)
+        mid = _Holder()
+        cl, hc = num_channels[-1], self.num_head_channels_[-1]
+        mid.resnet_1 = _resnet(cl, ted, cl, norm_num_groups, norm_eps)
+        mid.attention = _spatial_transformer(cl, cl // hc, hc, 1, norm_num_groups, norm_eps, cross_attention_dim)
+        mid.resnet_2 = _resnet(cl, ted, cl, norm_num_groups, norm_eps)
+        self.middle_block = mid
+        self._pk = None
+        return ted
+
+    # ---- packed-weight cache: rebuilt whenever parameters may have changed
+    def _invalidate(self):
+        self._pk = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = dict(state_dict)
+        # accept `controlnet_down_blocks.k.conv.weight` as well as the bare-conv spelling (Appendix A.8)
+        for k in list(sd.keys()):
+            if k.startswith(("controlnet_down_blocks.", "controlnet_mid_block.")) and ".conv." in k:
+                sd[k.replace(".conv.", ".")] = sd.pop(k)
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._pk = None
+        return r
+
+    def _resnets_in_order(self) -> List[_Holder]:
+        rs = []
+        for blk in self.down_blocks:
+            rs.extend(blk.resnets)
+        rs += [self.middle_block.resnet_1, self.middle_block.resnet_2]
+        if hasattr(self, "up_blocks"):
+            for blk in self.up_blocks:
+                rs.extend(blk.resnets)
+        return rs
+
+    def _pack(self):
+        dev = self.conv_in.conv.weight.device
+        if dev.type != "cuda":
+            raise CcnetError("ccnet_amd networks run on the GPU only: call .to('cuda') first (no CPU fallback)")
+        pk = {}
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
+
+        def pconv(conv: nn.Conv2d, cin_pad=None, cout_pad=None):
+            w = conv.weight.detach().float()
+            co, ci, r, _ = w.shape
+            cip, cop = cin_pad or ci, cout_pad or co
+            wp = torch.zeros(cop, r, r, cip, dtype=torch.float32, device=w.device)
+            wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+            b = torch.zeros(cop, dtype=torch.float32, device=w.device)
+            if conv.bias is not None:
+                b[:co] = conv.bias.detach().float()
+            return wp.reshape(cop, r * r * cip).to(BF16).contiguous(), b.contiguous()
+
+        def plin(w: torch.Tensor):
+            return w.detach().to(BF16).contiguous()
+
+        def pres(r: _Holder):
+            d = {"n1": (f32(r.norm1.weight), f32(r.norm1.bias)), "n2": (f32(r.norm2.weight), f32(r.norm2.bias)),
+                 "c1": pconv(r.conv1.conv), "c2": pconv(r.conv2.conv), "cout": r.cout,
+                 "skip": None if isinstance(r.skip_connection, nn.Identity) else pconv(r.skip_connection.conv)}
+            return d
+
+        def pattn(a: _Holder):
+            b = a.transformer_blocks[0]
+            inner = a.heads * a.head_ch
+            return {
+                "norm": (f32(a.norm.weight), f32(a.norm.bias)), "pin": pconv(a.proj_in.conv),
+                "pout": pconv(a.proj_out.conv), "heads": a.heads, "head_ch": a.head_ch, "inner": inner,
+                "ln1": (f32(b.norm1.weight), f32(b.norm1.bias)), "ln2": (f32(b.norm2.weight), f32(b.norm2.bias)),
+                "ln3": (f32(b.norm3.weight), f32(b.norm3.bias)),
+                "qkv1": plin(torch.cat([b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight], 0)),
+                "o1": (plin(b.attn1.to_out[0].weight), f32(b.attn1.to_out[0].bias)),
+                "q2": plin(b.attn2.to_q.weight),
+                "kv2": plin(torch.cat([b.attn2.to_k.weight, b.attn2.to_v.weight], 0)),
+                "o2": (plin(b.attn2.to_out[0].weight), f32(b.attn2.to_out[0].bias)),
+                "ff1": (plin(b.ff.linear1.weight), f32(b.ff.linear1.bias)),
+                "ff2": (plin(b.ff.linear2.weight), f32(b.ff.linear2.bias)),
+            }
+
+        pk["conv_in"] = (f32(self.conv_in.conv.weight), f32(self.conv_in.conv.bias))
+        pk["te0"] = (f32(self.time_embed[0].weight), f32(self.time_embed[0].bias))
+        pk["te2"] = (f32(self.time_embed[2].weight), f32(self.time_embed[2].bias))
+        c0 = self.block_out_channels[0]
+        half = c0 // 2
+        pk["freqs"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        if self.num_class_embeds is not None:
+            ce = self.class_embedding
+            if isinstance(ce, nn.Embedding):
+                pk["class_table"] = f32(ce.weight)
+            else:
+                pk["ce0"] = (f32(ce[0].weight), f32(ce[0].bias))
+                pk["ce2"] = (f32(ce[2].weight), f32(ce[2].bias))
+        # all time_emb_proj layers as one fp32 matrix -> one launch per forward
+        rs = self._resnets_in_order()
+        pk["tproj_w"] = torch.cat([f32(r.time_emb_proj.weight) for r in rs], 0).contiguous()
+        pk["tproj_b"] = torch.cat([f32(r.time_emb_proj.bias) for r in rs], 0).contiguous()
+        offs, o = [], 0
+        for r in rs:
+            offs.append(o)
+            o += r.cout
+        pk["tproj_off"] = {id(r): off for r, off in zip(rs, offs)}
+        pk["res"] = {id(r): pres(r) for r in rs}
+        atts = []
+        for blk in self.down_blocks:
+            if hasattr(blk, "attentions"):
+                atts.extend(blk.attentions)
+        atts.append(self.middle_block.attention)
+        if hasattr(self, "up_blocks"):
+            for blk in self.up_blocks:
+                if hasattr(blk, "attentions"):
+                    atts.extend(blk.attentions)
+        pk["att"] = {id(a): pattn(a) for a in atts}
+        pk["att_order"] = atts
+        pk["down"] = {id(b): pconv(b.downsampler.op.conv) for b in self.down_blocks if b.downsampler is not None}
+        self._pack_extra(pk, pconv, f32)
+        self._pk = pk
+        return pk
+
+    def _pack_extra(self, pk, pconv, f32):
+        pass
+
+    # ---- lowering helpers
+    def _embedding(self, pk, timesteps, class_labels, B):
+        dev = pk["freqs"].device
+        t = timesteps.to(device=dev, dtype=torch.float32).reshape(-1)
+        if t.numel() not in (1, B):
+            raise ValueError(f"timesteps must have 1 or {B} elements, got {t.numel()}")
+        c0 = self.block_out_channels[0]
+        t_emb = ops.timestep_embedding(t, B, c0, pk["freqs"])
+        h = ops.linear_f32(t_emb, pk["te0"][0], pk["te0"][1], silu_out=True)
+        add = None
+        if self.num_class_embeds is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            if "class_table" in pk:
+                add = pk["class_table"][class_labels.to(dev).long().reshape(-1)]
+            else:
+                cl = class_labels.to(device=dev, dtype=torch.float32).reshape(B, 1).contiguous()
+                c1 = ops.linear_f32(cl, pk["ce0"][0], pk["ce0"][1], silu_out=True)
+                add = ops.linear_f32(c1, pk["ce2"][0], pk["ce2"][1])
+        emb = ops.linear_f32(h, pk["te2"][0], pk["te2"][1], add=add)
+        # every resnet's time_emb_proj(silu(emb)) in one launch; resnets take column slices
+        return ops.linear_f32(emb, pk["tproj_w"], pk["tproj_b"], silu_in=True)
+
+    def _context(self, context, B):
+        if context is None:
+            raise ValueError("context is required (with_conditioning=True)")
+        if context.shape[0] != B:
+            raise ValueError(f"context batch {context.shape[0]} != input batch {B}")
+        S, D = context.shape[1], context.shape[2]
+        if D % 64:
+            raise CcnetError("cross_attention_dim must be a multiple of 64 for the MI355X lowering")
+        c = context.reshape(B * S, D, 1, 1)
+        a = ops.nchw_to_act(c, D)  # fp32 -> bf16 rows
+        return a.t, S
+
+    def context_kv(self, context):
+        """Cross-attention K/V of `context` for every SpatialTransformer, in execution order.  They do not depend
+        on the timestep, so a sampler may compute them once per batch and pass them back via `_ctx_kv`."""
+        pk = self._pk or self._pack()
+        ctx, S = self._context(context, context.shape[0])
+        out = []
+        for a in pk["att_order"]:
+            p = pk["att"][id(a)]
+            out.append(ops.linear(ctx, p["kv2"], None, 2 * p["inner"], ctx.shape[1]))
+        return out, S
+
+    def _run_resnet(self, pk, r, x: Act, tall, x2: Optional[Act] = None, res2: Optional[Act] = None):
+        p = pk["res"][id(r)]
+        g, eps = self.norm_num_groups, self.norm_eps
+        off = pk["tproj_off"][id(r)]
+        cout = p["cout"]
+        h = ops.groupnorm(x, p["n1"][0], p["n1"][1], g, eps, True, x2=x2)
+        h = ops.conv(h, p["c1"][0], p["c1"][1], cout, R=3, rowvec=tall[:, off:off + cout])
+        h = ops.groupnorm(h, p["n2"][0], p["n2"][1], g, eps, True)
+        if p["skip"] is None:
+            skip = x
+        else:
+            skip = ops.conv(x, p["skip"][0], p["skip"][1], cout, R=1, pad=0, x2=x2)
+        return ops.conv(h, p["c2"][0], p["c2"][1], cout, R=3, res1=skip, res2=res2)
+
+    def _run_attn(self, pk, a, x: Act, kv: torch.Tensor, S: int, res2: Optional[Act] = None):
+        p = pk["att"][id(a)]
+        C_, inner, heads, hc = x.C, p["inner"], p["heads"], p["head_ch"]
+        if hc != 64:
+            raise CcnetError(f"attention head dim {hc}: only num_head_channels == 64 is lowered to the flash kernel "
+                             "in this round (SD-2.1 geometry); see DESIGN.md 'out of scope'")
+        B, T = x.N, x.H * x.W
+        scale = 1.0 / math.sqrt(hc)
+        h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.norm_eps, False)
+        t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
+        n1 = ops.layernorm(t, inner, *p["ln1"])
+        qkv = ops.linear(n1, p["qkv1"], None, 3 * inner, inner)
+        o = ops.attention_d64(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, heads, T, T, scale)
+        t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
+        n2 = ops.layernorm(t, inner, *p["ln2"])
+        q = ops.linear(n2, p["q2"], None, inner, inner)
+        o = ops.attention_d64(q, kv[:, :inner], kv[:, inner:], B, heads, T, S, scale)
+        t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
+        n3 = ops.layernorm(t, inner, *p["ln3"])
+        f = ops.linear(n3, p["ff1"][0], p["ff1"][1], 8 * inner, inner)
+        gl = ops.geglu(f, 4 * inner)
+        t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
+        ta = Act(t, x.N, x.H, x.W, inner)
+        return ops.conv(ta, p["pout"][0], p["pout"][1], C_, R=1, pad=0, res1=x, res2=res2)
+
+    def _encode(self, pk, h: Act, tall, kvs, S, add: Optional[Sequence[Act]] = None):
+        """Down blocks. Returns (h, skips); when `add` is given skips[k] = s_k + add[k] (written by the same launch
+        that produces s_k) while the trunk continues with the un-added s_k, as upstream does."""
+        skips: List[Act] = []
+        k = 1  # skip 0 is the conv_in output, handled by the caller
+        ai = 0
+
+        def pick(out):
+            nonlocal k
+            if add is not None:
+                o, o2 = out
+                skips.append(o2)
+            else:
+                o = out
+                skips.append(o)
+            k += 1
+            return o
+
+        for blk in self.down_blocks:
+            has_att = hasattr(blk, "attentions")
+            for j, r in enumerate(blk.resnets):
+                r2 = add[k] if (add is not None) else None
+                if has_att:
+                    h = self._run_resnet(pk, r, h, tall)
+                    h = pick(self._run_attn(pk, blk.attentions[j], h, kvs[ai], S, res2=r2))
+                    ai += 1
+                else:
+                    h = pick(self._run_resnet(pk, r, h, tall, res2=r2))
+            if blk.downsampler is not None:
+                w, b = pk["down"][id(blk)]
+                r2 = add[k] if (add is not None) else None
+                h = pick(ops.conv(h, w, b, h.C, R=3, stride=2, res2=r2))
+        return h, skips, ai
+
+    def _mid(self, pk, h, tall, kv, S, res2=None):
+        m = self.middle_block
+        h = self._run_resnet(pk, m.resnet_1, h, tall)
+        h = self._run_attn(pk, m.attention, h, kv, S)
+        return self._run_resnet(pk, m.resnet_2, h, tall, res2=res2)
+
+
+def _as_act(t, N, dev) -> Act:
+    """Accept a residual as Act, as a zero-copy channels-last bf16 NCHW view, or as any NCHW tensor."""
+    if isinstance(t, Act):
+        return t
+    if t.dim() != 4:
+        raise ValueError("residual must be NCHW")
+    n, c, h, w = t.shape
+    if t.dtype == BF16 and t.is_cuda and t.stride(1) == 1 and t.stride(3) == t.stride(0) // (h * w) \
+            and t.stride(2) == w * t.stride(3):
+        ld = t.stride(3)
+        base = torch.as_strided(t, (n * h * w, c), (ld, 1), t.storage_offset())
+        return Act(base, n, h, w, c)
+    return ops.nchw_to_act(t.to(dev), c)
+
+
+def _act_view_nchw(a: Act) -> torch.Tensor:
+    """Zero-copy NCHW-shaped (channels-last strided) bf16 view of an activation."""
+    return a.t.view(a.N, a.H, a.W, a.t.shape[1])[..., : a.C].permute(0, 3, 1, 2)
+
+
+class DiffusionModelUNet(_Trunk):
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_res_blocks=(2, 2, 2, 2),
+                 num_channels=(32, 64, 64, 64), attention_levels=(False, False, True, True),
+                 norm_num_groups: int = 32, norm_eps: float = 1e-6, resblock_updown: bool = False,
+                 num_head_channels=8, with_conditioning: bool = False, transformer_num_layers: int = 1,
+                 cross_attention_dim: Optional[int] = None, num_class_embeds: Optional[int] = None,
+                 upcast_attention: bool = False, use_flash_attention: bool = False):
+        super().__init__()
+        if spatial_dims != 2:
+            raise NotImplementedError("only spatial_dims=2 is on the ccnet hot path")
+        if resblock_updown:
+            raise NotImplementedError("resblock_updown=True")
+        if in_channels > 8 or out_channels > 8:
+            raise CcnetError("in/out channels > 8 are not lowered (latent channels are 3 or 4 in every ccnet config)")
+        ted = self._build_trunk(in_channels, num_res_blocks, num_channels, attention_levels, norm_num_groups,
+                                norm_eps, num_head_channels, with_conditioning, transformer_num_layers,
+                                cross_attention_dim, num_class_embeds)
+        self.out_channels = out_channels
+        n = len(num_channels)
+        rev_ch = list(reversed(num_channels))
+        rev_res = list(reversed(self.num_res_blocks_))
+        rev_att = list(reversed(self.attention_levels_))
+        rev_hc = list(reversed(self.num_head_channels_))
+        self.up_blocks = nn.ModuleList()
+        out_ch = rev_ch[0]
+        for i in range(n):
+            prev, out_ch = out_ch, rev_ch[i]
+            in_ch = rev_ch[min(i + 1, n - 1)]
+            blk = _Holder()
+            blk.resnets = nn.ModuleList()
+            att = bool(rev_att[i]) and with_conditioning
+            atts = []
+            nres = rev_res[i] + 1
+            for j in range(nres):
+                skip = in_ch if j == nres - 1 else out_ch
+                rin = prev if j == 0 else out_ch
+                blk.resnets.append(_resnet(rin + skip, ted, out_ch, norm_num_groups, norm_eps))
+                if att:
+                    atts.append(_spatial_transformer(out_ch, out_ch // rev_hc[i], rev_hc[i], 1, norm_num_groups,
+                                                     norm_eps, cross_attention_dim))
+            if att:
+                blk.attentions = nn.ModuleList(atts)
+            if i != n - 1:
+                us = _Holder()
+                us.conv = _convolution(out_ch, out_ch)
+                blk.upsampler = us
+            else:
+                blk.upsampler = None
+            self.up_blocks.append(blk)
+        self.out = nn.Sequential(nn.GroupNorm(norm_num_groups, num_channels[0], eps=norm_eps, affine=True), nn.SiLU(),
+                                 _zero(_convolution(num_channels[0], out_channels)))
+
+    def _pack_extra(self, pk, pconv, f32):
+        pk["up"] = {id(b): pconv(b.upsampler.conv.conv) for b in self.up_blocks if b.upsampler is not None}
+        pk["out_norm"] = (f32(self.out[0].weight), f32(self.out[0].bias))
+        w = self.out[2].conv.weight.detach().float()  # [Cout, C0, 3, 3] -> bf16 [Cout][9][C0]
+        dev = pk["freqs"].device
+        pk["out_conv"] = (w.permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).to(BF16).contiguous().to(dev),
+                          f32(self.out[2].conv.bias))
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
+                class_labels: Optional[torch.Tensor] = None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, _ctx_kv=None, _x_batch: Optional[int] = None):
+        """x fp32 NCHW [Bx, Cin, h, w]; the network batch is `_x_batch or Bx` (image n reads x[n % Bx], which lets a
+        CFG sampler pass the un-duplicated latent).  Returns fp32 NCHW [B, Cout, h, w]."""
+        pk = self._pk or self._pack()
+        dev = pk["freqs"].device
+        if not x.is_cuda:
+            raise CcnetError("ccnet_amd.DiffusionModelUNet runs on the GPU only (no CPU fallback)")
+        x = x.contiguous().float()
+        B = _x_batch or x.shape[0]
+        tall = self._embedding(pk, timesteps, class_labels, B)
+        if _ctx_kv is None:
+            kvs, S = self.context_kv(context)
+        else:
+            kvs, S = _ctx_kv
+        c0 = self.block_out_channels[0]
+        add = None
+        if down_block_additional_residuals is not None:
+            add = [_as_act(t, B, dev) for t in down_block_additional_residuals]
+        w, b = pk["conv_in"]
+        h = ops.conv_in_small(x, B, w, b, c0, c0)
+        if add is not None:
+            s0 = ops.conv_in_small(x, B, w, b, c0, c0, res=add[0])
+        else:
+            s0 = h
+        h, skips, ai = self._encode(pk, h, tall, kvs, S, add)
+        skips = [s0] + skips
+        if add is not None and len(add) != len(skips):
+            raise ValueError(f"expected {len(skips)} down_block_additional_residuals, got {len(add)}")
+        mid_add = _as_act(mid_block_additional_residual, B, dev) if mid_block_additional_residual is not None else None
+        h = self._mid(pk, h, tall, kvs[ai], S, res2=mid_add)
+        if mid_add is not None:
+            h = h[1]
+        ai += 1
+        for blk in self.up_blocks:
+            has_att = hasattr(blk, "attentions")
+            for j, r in enumerate(blk.resnets):
+                s = skips.pop()
+                h = self._run_resnet(pk, r, h, tall, x2=s)
+                if has_att:
+                    h = self._run_attn(pk, blk.attentions[j], h, kvs[ai], S)
+                    ai += 1
+            if blk.upsampler is not None:
+                uw, ub = pk["up"][id(blk)]
+                h = ops.conv(h, uw, ub, h.C, R=3, ups=2)
+        h = ops.groupnorm(h, pk["out_norm"][0], pk["out_norm"][1], self.norm_num_groups, self.norm_eps, True)
+        return ops.conv_out_small(h, pk["out_conv"][0], pk["out_conv"][1], self.out_channels)
+
+
+class ControlNet(_Trunk):
+    def __init__(self, spatial_dims: int, in_channels: int, num_res_blocks=(2, 2, 2, 2),
+                 num_channels=(32, 64, 64, 64), attention_levels=(False, False, True, True),
+                 norm_num_groups: int = 32, norm_eps: float = 1e-6, resblock_updown: bool = False,
+                 num_head_channels=8, with_conditioning: bool = False, transformer_num_layers: int = 1,
+                 cross_attention_dim: Optional[int] = None, num_class_embeds: Optional[int] = None,
+                 upcast_attention: bool = False, use_flash_attention: bool = False,
+                 conditioning_embedding_in_channels: int = 1,
+                 conditioning_embedding_num_channels: Sequence[int] = (16, 32, 96, 256)):
+        super().__init__()
+        if spatial_dims != 2:
+            raise NotImplementedError("only spatial_dims=2 is on the ccnet hot path")
+        if resblock_updown:
+            raise NotImplementedError("resblock_updown=True")
+        if in_channels > 8 or conditioning_embedding_in_channels > 8:
+            raise CcnetError("in_channels / conditioning_embedding_in_channels > 8 are not lowered")
+        self._build_trunk(in_channels, num_res_blocks, num_channels, attention_levels, norm_num_groups, norm_eps,
+                          num_head_channels, with_conditioning, transformer_num_layers, cross_attention_dim,
+                          num_class_embeds)
+        ce = _Holder()
+        ech = tuple(conditioning_embedding_num_channels)
+        ce.conv_in = _convolution(conditioning_embedding_in_channels, ech[0])
+        ce.blocks = nn.ModuleList()
+        for i in range(len(ech) - 1):
+            ce.blocks.append(_convolution(ech[i], ech[i]))
+            ce.blocks.append(_convolution(ech[i], ech[i + 1], 3, 2, 1))
+        ce.conv_out = _zero(_convolution(ech[-1], num_channels[0]))
+        self.controlnet_cond_embedding = ce
+        self.cond_channels = ech
+        n = len(num_channels)
+        self.controlnet_down_blocks = nn.ModuleList()
+        out_ch = num_channels[0]
+        self.controlnet_down_blocks.append(_zero(nn.Conv2d(out_ch, out_ch, 1)))
+        for i in range(n):
+            out_ch = num_channels[i]
+            for _ in range(self.num_res_blocks_[i]):
+                self.controlnet_down_blocks.append(_zero(nn.Conv2d(out_ch, out_ch, 1)))
+            if i != n - 1:
+                self.controlnet_down_blocks.append(_zero(nn.Conv2d(out_ch, out_ch, 1)))
+        self.controlnet_mid_block = _zero(nn.Conv2d(num_channels[-1], num_channels[-1], 1))
+
+    def _pack_extra(self, pk, pconv, f32):
+        ce = self.controlnet_cond_embedding
+        pk["ce_in"] = (f32(ce.conv_in.conv.weight), f32(ce.conv_in.conv.bias))
+        blocks = []
+        for b in ce.blocks:
+            ci, co = b.conv.in_channels, b.conv.out_channels
+            blocks.append(pconv(b.conv, _pad64(ci), _pad64(co)) + (b.conv.stride[0], _pad64(co)))
+        pk["ce_blocks"] = blocks
+        pk["ce_out"] = pconv(ce.conv_out.conv, _pad64(ce.conv_out.conv.in_channels), None)
+        pk["zero"] = [pconv(c) for c in self.controlnet_down_blocks]
+        pk["zero_mid"] = pconv(self.controlnet_mid_block)
+
+    @torch.no_grad()
+    def cond_embedding(self, controlnet_cond: torch.Tensor) -> Act:
+        """controlnet_cond_embedding(cond): step-invariant, so a sampler computes it once per image."""
+        pk = self._pk or self._pack()
+        c = controlnet_cond.contiguous().float()
+        if not c.is_cuda:
+            raise CcnetError("ccnet_amd.ControlNet runs on the GPU only (no CPU fallback)")
+        e0 = self.cond_channels[0]
+        h = ops.conv_in_small(c, c.shape[0], pk["ce_in"][0], pk["ce_in"][1], e0, _pad64(e0), act=1)
+        for w, b, stride, cop in pk["ce_blocks"]:
+            h = ops.conv(h, w, b, cop, R=3, stride=stride, act=1)
+        w, b = pk["ce_out"]
+        return ops.conv(h, w, b, self.block_out_channels[0], R=3)
+
+    @torch.no_grad()
+    def forward_native(self, x, timesteps, controlnet_cond, conditioning_scale: float = 1.0, context=None,
+                       class_labels=None, _ctx_kv=None, _cond_emb: Optional[Act] = None,
+                       _x_batch: Optional[int] = None):
+        """Same computation as forward(); returns the residuals as NHWC bf16 `Act`s."""
+        pk = self._pk or self._pack()
+        if not x.is_cuda:
+            raise CcnetError("ccnet_amd.ControlNet runs on the GPU only (no CPU fallback)")
+        x = x.contiguous().float()
+        B = _x_batch or x.shape[0]
+        tall = self._embedding(pk, timesteps, class_labels, B)
+        if _ctx_kv is None:
+            kvs, S = self.context_kv(context)
+        else:
+            kvs, S = _ctx_kv
+        ce = _cond_emb if _cond_emb is not None else self.cond_embedding(controlnet_cond)
+        c0 = self.block_out_channels[0]
+        w, b = pk["conv_in"]
+        h = ops.conv_in_small(x, B, w, b, c0, c0, res=ce)  # h = conv_in(x) + cond_emb (image n uses ce[n % ce.N])
+        s0 = h
+        h, skips, ai = self._encode(pk, h, tall, kvs, S)
+        skips = [s0] + skips
+        h = self._mid(pk, h, tall, kvs[ai], S)
+        sc = float(conditioning_scale)
+        down = [ops.conv(s, zw, zb, s.C, R=1, pad=0, scale=sc) for s, (zw, zb) in zip(skips, pk["zero"])]
+        zw, zb = pk["zero_mid"]
+        mid = ops.conv(h, zw, zb, h.C, R=1, pad=0, scale=sc)
+        return down, mid
+
+    def forward(self, x, timesteps, controlnet_cond, conditioning_scale: float = 1.0, context=None,
+                class_labels=None):
+        """Returns (list of NCHW-shaped bf16 tensors, mid) -- channels-last views of the NHWC activations, which
+        DiffusionModelUNet.forward consumes without a copy."""
+        down, mid = self.forward_native(x, timesteps, controlnet_cond, conditioning_scale, context, class_labels)
+        return [_act_view_nchw(d) for d in down], _act_view_nchw(mid)
+
+
+def adjust_class_embedding(model: nn.Module) -> None:
+    """util.py:1094-1132: continuous acquisition-time conditioning -- Linear(1, ted) -> SiLU -> Linear(ted, ted)."""
+    name = str(model.__class__.__name__)
+    if not (("DiffusionModelUNet" in name or "ControlNet" in name) and hasattr(model, "block_out_channels")):
+        raise ValueError(f"{name} has neither key ('x' AND 'block_out_channels') nor key 'config'. "
+                         f"Current diffusion model keys: {model.__dict__.keys()}")
+    model.num_class_embeds = int(99999)
+    ted = model.block_out_channels[0] * 4
+    dev = model.conv_in.conv.weight.device
+    model.class_embedding = nn.Sequential(nn.Linear(1, ted), nn.SiLU(), nn.Linear(ted, ted)).to(dev)
+    model._invalidate()
+
+
+# --------------------------------------------------------------------------- AutoencoderKL (stage 1)
+def _ae_resblock(cin, cout, groups, eps) -> _Holder:
+    h = _Holder()
+    h.norm1 = nn.GroupNorm(groups, cin, eps=eps, affine=True)
+    h.conv1 = _convolution(cin, cout)
+    h.norm2 = nn.GroupNorm(groups, cout, eps=eps, affine=True)
+    h.conv2 = _convolution(cout, cout)
+    h.nin_shortcut = _convolution(cin, cout, 1, 1, 0) if cin != cout else nn.Identity()
+    h.kind, h.cin, h.cout = "res", cin, cout
+    return h
+
+
+def _ae_sample(ch, kind) -> _Holder:
+    h = _Holder()
+    h.conv = _convolution(ch, ch, 3, 2 if kind == "down" else 1, 0 if kind == "down" else 1)
+    h.kind = kind
+    return h
+
+
+class AutoencoderKL(nn.Module):
+    """monai-generative AutoencoderKL lowered to the same conv / GroupNorm kernels."""
+
+    def __init__(self, spatial_dims: int, in_channels: int = 1, out_channels: int = 1, num_res_blocks=(2, 2, 2, 2),
+                 num_channels=(32, 64, 64, 64), attention_levels=(False, False, True, True),
+                 latent_channels: int = 3, norm_num_groups: int = 32, norm_eps: float = 1e-6,
+                 with_encoder_nonlocal_attn: bool = True, with_decoder_nonlocal_attn: bool = True,
+                 use_flash_attention: bool = False):
+        super().__init__()
+        if spatial_dims != 2:
+            raise NotImplementedError("only spatial_dims=2")
+        if any(attention_levels) or with_encoder_nonlocal_attn or with_decoder_nonlocal_attn:
+            raise NotImplementedError("AutoencoderKL attention blocks are not lowered: every ccnet stage-1 config "
+                                      "(configs/stage1/aekl_v0.yaml:14-16) disables them")
+        if in_channels > 8 or out_channels > 8 or latent_channels > 8:
+            raise CcnetError("in/out/latent channels > 8 are not lowered")
+        if any(c % 64 for c in num_channels):
+            raise CcnetError("the MI355X lowering needs every entry of num_channels to be a multiple of 64")
+        n = len(num_channels)
+        nrb = _tuple(num_res_blocks, n)
+        self.num_channels = list(num_channels)
+        self.latent_channels, self.in_channels, self.out_channels = latent_channels, in_channels, out_channels
+        self.norm_num_groups, self.norm_eps = norm_num_groups, norm_eps
+        g, eps = norm_num_groups, norm_eps
+        # encoder.blocks / decoder.blocks are flat lists upstream (keys `encoder.blocks.{i}....`)
+        enc = [_convolution(in_channels, num_channels[0])]
+        out_ch = num_channels[0]
+        for i in range(n):
+            in_ch, out_ch = out_ch, num_channels[i]
+            for _ in range(nrb[i]):
+                enc.append(_ae_resblock(in_ch, out_ch, g, eps))
+                in_ch = out_ch
+            if i != n - 1:
+                enc.append(_ae_sample(in_ch, "down"))
+        enc.append(nn.GroupNorm(g, num_channels[-1], eps=eps, affine=True))
+        enc.append(_convolution(num_channels[-1], latent_channels))
+        self.encoder = _Holder()
+        self.encoder.blocks = nn.ModuleList(enc)
+        rev = list(reversed(num_channels))
+        rev_res = list(reversed(nrb))
+        dec = [_convolution(latent_channels, rev[0])]
+        out_ch = rev[0]
+        for i in range(n):
+            in_ch, out_ch = out_ch, rev[i]
+            for _ in range(rev_res[i]):
+                dec.append(_ae_resblock(in_ch, out_ch, g, eps))
+                in_ch = out_ch
+            if i != n - 1:
+                dec.append(_ae_sample(in_ch, "up"))
+        dec.append(nn.GroupNorm(g, in_ch, eps=eps, affine=True))
+        dec.append(_convolution(in_ch, out_channels))
+        self.decoder = _Holder()
+        self.decoder.blocks = nn.ModuleList(dec)
+        self.quant_conv_mu = _convolution(latent_channels, latent_channels, 1, 1, 0)
+        self.quant_conv_log_sigma = _convolution(latent_channels, latent_channels, 1, 1, 0)
+        self.post_quant_conv = _convolution(latent_channels, latent_channels, 1, 1, 0)
+        self._pk = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._pk = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._pk = None
+        return r
+
+    def _pack(self):
+        dev = self.post_quant_conv.conv.weight.device
+        if dev.type != "cuda":
+            raise CcnetError("ccnet_amd.AutoencoderKL runs on the GPU only: call .to('cuda') first (no CPU fallback)")
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()
+
+        def pconv(conv: nn.Conv2d):
+            w = conv.weight.detach().float()
+            co, ci, r, _ = w.shape
+            return w.permute(0, 2, 3, 1).reshape(co, r * r * ci).to(BF16).contiguous(), f32(conv.bias)
+
+        pk = {}
+        for side in ("encoder", "decoder"):
+            lst = []
+            blocks = list(getattr(self, side).blocks)
+            for i, b in enumerate(blocks):
+                if isinstance(b, nn.GroupNorm):
+                    lst.append(("norm", f32(b.weight), f32(b.bias)))
+                elif getattr(b, "kind", None) == "res":
+                    lst.append(("res", {
+                        "n1": (f32(b.norm1.weight), f32(b.norm1.bias)), "n2": (f32(b.norm2.weight), f32(b.norm2.bias)),
+                        "c1": pconv(b.conv1.conv), "c2": pconv(b.conv2.conv), "cout": b.cout,
+                        "skip": None if isinstance(b.nin_shortcut, nn.Identity) else pconv(b.nin_shortcut.conv)}))
+                elif getattr(b, "kind", None) in ("down", "up"):
+                    lst.append((b.kind,) + pconv(b.conv.conv))
+                elif i == 0:  # first conv: tiny Cin, fp32 direct kernel
+                    lst.append(("conv_first", f32(b.conv.weight), f32(b.conv.bias), b.conv.out_channels))
+                else:         # last conv: tiny Cout
+                    w = b.conv.weight.detach().float()
+                    lst.append(("conv_last", w.permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).to(BF16)
+                                .contiguous().to(dev), f32(b.conv.bias), w.shape[0]))
+            pk[side] = lst
+        for nm in ("quant_conv_mu", "quant_conv_log_sigma", "post_quant_conv"):
+            c = getattr(self, nm).conv
+            pk[nm] = (f32(c.weight).reshape(c.out_channels, c.in_channels), f32(c.bias))
+        self._pk = pk
+        return pk
+
+    def _run(self, lst, x: torch.Tensor) -> torch.Tensor:
+        g, eps = self.norm_num_groups, self.norm_eps
+        h = None
+        for item in lst:
+            kind = item[0]
+            if kind == "conv_first":
+                _, w, b, cout = item
+                h = ops.conv_in_small(x, x.shape[0], w, b, cout, cout)
+            elif kind == "res":
+                p = item[1]
+                t = ops.groupnorm(h, p["n1"][0], p["n1"][1], g, eps, True)
+                t = ops.conv(t, p["c1"][0], p["c1"][1], p["cout"], R=3)
+                t = ops.groupnorm(t, p["n2"][0], p["n2"][1], g, eps, True)
+                skip = h if p["skip"] is None else ops.conv(h, p["skip"][0], p["skip"][1], p["cout"], R=1, pad=0)
+                h = ops.conv(t, p["c2"][0], p["c2"][1], p["cout"], R=3, res1=skip)
+            elif kind == "down":  # F.pad(x, (0,1,0,1)) + 3x3 stride-2 pad-0 conv
+                h = ops.conv(h, item[1], item[2], h.C, R=3, stride=2, pad=0, out_hw=(h.H // 2, h.W // 2))
+            elif kind == "up":
+                h = ops.conv(h, item[1], item[2], h.C, R=3, ups=2)
+            elif kind == "norm":  # upstream applies no nonlinearity after the final GroupNorm
+                h = ops.groupnorm(h, item[1], item[2], g, eps, False)
+            elif kind == "conv_last":
+                return ops.conv_out_small(h, item[1], item[2], item[3])
+        raise CcnetError("malformed AutoencoderKL block list")
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        pk = self._pk or self._pack()
+        if not z.is_cuda:
+            raise CcnetError("ccnet_amd.AutoencoderKL runs on the GPU only (no CPU fallback)")
+        z = z.contiguous().float()
+        zq = ops.pointwise_nchw(z, pk["post_quant_conv"][0], pk["post_quant_conv"][1], 0)
+        return self._run(pk["decoder"], zq)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor):
+        pk = self._pk or self._pack()
+        if not x.is_cuda:
+            raise CcnetError("ccnet_amd.AutoencoderKL runs on the GPU only (no CPU fallback)")
+        h = self._run(pk["encoder"], x.contiguous().float())
+        z_mu = ops.pointwise_nchw(h, pk["quant_conv_mu"][0], pk["quant_conv_mu"][1], 0)
+        z_sigma = ops.pointwise_nchw(h, pk["quant_conv_log_sigma"][0], pk["quant_conv_log_sigma"][1], 1)
+        return z_mu, z_sigma
+
+    def sampling(self, z_mu: torch.Tensor, z_sigma: torch.Tensor, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        eps = torch.randn_like(z_sigma) if eps is None else eps
+        return ops.axpy_f32(z_mu, eps, z_sigma)
+
+    def forward(self, x: torch.Tensor):
+        z_mu, z_sigma = self.encode(x)
+        z = self.sampling(z_mu, z_sigma)
+        return self.decode(z), z_mu, z_sigma

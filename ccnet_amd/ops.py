@@ -260,6 +260,27 @@ def to_uint8(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pointwise_nchw(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int) -> torch.Tensor:
+    lib = _l.load()
+    _need_cuda(x, w)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=x.device)
+    _l.check(lib.ccnet_pointwise_nchw_f32(x.data_ptr(), N, Cin, H * W, w.data_ptr(), _ptr(bias), Cout, mode,
+                                          out.data_ptr(), _stream()), "pointwise_nchw")
+    return out
+
+
+def axpy_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    lib = _l.load()
+    _need_cuda(a, b, c)
+    a, b, c = a.contiguous().float(), b.contiguous().float(), c.contiguous().float()
+    out = torch.empty_like(a)
+    _l.check(lib.ccnet_axpy_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.numel(), out.data_ptr(), _stream()),
+             "axpy_f32")
+    return out
+
+
 def prof_enable(on: bool) -> None:
     _l.load().ccnet_prof_enable(int(on))
 

@@ -1,0 +1,139 @@
+"""The ccnet sampling loop on the HIP path.
+
+Mirrors, with the same names and argument meaning:
+  * `sample_from_controlnet`  -- util.py:934-962
+  * `sample_from_ldm`         -- util.py:1043-1092
+  * the per-sample loop of run_controlnet_inference.py:211-256 (`sample`, `Sampler`)
+  * `interval_mapping` -> uint8 of save_controlnet_inference_sample, util.py:1162-1173,1412-1416 (`to_uint8`)
+
+`Sampler` is the MI355X-first form of that loop for a batch of B images: the latent is NOT duplicated for
+classifier-free guidance (the edge conv reads image n % B), the step-invariant work is hoisted out of the N-step
+loop (ControlNet conditioning embedding, every cross-attention K/V projection of the prompt embeddings,
+SURVEY.md Appendix E), ControlNet residuals stay NHWC bf16 and are added inside the UNet kernels that produce the
+skip tensors, and CFG + scheduler step are one kernel.  Results are the same computation the reference performs.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .lib import CcnetError
+from .schedulers import DDPMScheduler
+
+
+def sample_from_controlnet(controlnet, noisy_e, controlnet_cond, timesteps, prompt_embeds, class_labels=None,
+                           conditioning_scale=1.0):
+    if class_labels is not None and len(class_labels.shape) == 2 and class_labels.shape[0] == 1 \
+            and class_labels.shape[1] != 1:
+        class_labels = torch.squeeze(class_labels, dim=0)  # (1, bs) -> (bs)
+    if class_labels is not None and len(class_labels.shape) == 1:
+        class_labels = torch.unsqueeze(class_labels, dim=1)  # (bs) -> (bs, 1)
+    if hasattr(controlnet, "x") or "ControlNetModel" not in str(controlnet.__class__.__name__):
+        return controlnet(x=noisy_e, timesteps=timesteps, context=prompt_embeds, controlnet_cond=controlnet_cond,
+                          conditioning_scale=conditioning_scale, class_labels=class_labels)
+    raise NotImplementedError("diffusers ControlNetModel kwargs dialect: only the monai-generative surface is "
+                              "implemented (SURVEY.md section 8(f) item 1)")
+
+
+def sample_from_ldm(model, noisy_e, timesteps, prompt_embeds, down_block_res_samples=None, mid_block_res_sample=None,
+                    class_labels=None):
+    if class_labels is not None and class_labels.shape[0] == 1 and class_labels.shape[0] != noisy_e.shape[0]:
+        class_labels = torch.unsqueeze(torch.squeeze(class_labels, dim=0), dim=1)
+    if hasattr(model, "x") or "DiffusionModelUNet" in str(model.__class__.__name__):
+        if down_block_res_samples is None or mid_block_res_sample is None:
+            return model(x=noisy_e, timesteps=timesteps, context=prompt_embeds, class_labels=class_labels)
+        return model(x=noisy_e, timesteps=timesteps, context=prompt_embeds, class_labels=class_labels,
+                     down_block_additional_residuals=down_block_res_samples,
+                     mid_block_additional_residual=mid_block_res_sample)
+    raise NotImplementedError("diffusers UNet2DConditionModel kwargs dialect: only the monai-generative surface is "
+                              "implemented (SURVEY.md section 8(f) item 1)")
+
+
+def to_uint8(sample: torch.Tensor) -> torch.Tensor:
+    """[-1,1] -> [0,1] clip -> rint(x255) -> uint8, channel 0 (util.py:1412-1416). Returns [B, H, W] uint8 on GPU."""
+    return ops.to_uint8(sample)
+
+
+class Sampler:
+    """Batched ControlNet+UNet sampler with CFG; one instance per (controlnet, diffusion, scheduler)."""
+
+    def __init__(self, controlnet, diffusion, scheduler, stage1=None, guidance_scale: Optional[float] = None,
+                 conditioning_scale: float = 1.0, scale_factor: float = 0.01, cfg: bool = True):
+        self.controlnet, self.diffusion, self.scheduler, self.stage1 = controlnet, diffusion, scheduler, stage1
+        self.guidance_scale = guidance_scale
+        self.conditioning_scale = conditioning_scale
+        self.scale_factor = scale_factor
+        self.cfg = cfg  # run the [uncond, text] double batch as the reference does (run_controlnet_inference.py:219)
+
+    @torch.no_grad()
+    def prepare(self, cond: torch.Tensor, prompt_embeds: torch.Tensor, empty_prompt_embeds: torch.Tensor,
+                acquisition_time: Optional[torch.Tensor] = None):
+        """Step-invariant state for a batch: cond (B,1,H,W) in [-1,1]; prompt_embeds (B,77,D);
+        empty_prompt_embeds (1,77,D); acquisition_time (B,) seconds or None."""
+        if not cond.is_cuda:
+            raise CcnetError("Sampler inputs must be on the GPU (no CPU path)")
+        B = cond.shape[0]
+        if self.cfg:
+            # [uncond x B, text x B]: empty prompt first (run_controlnet_inference.py:207-208)
+            ctx = torch.cat([empty_prompt_embeds.to(prompt_embeds).expand(B, -1, -1), prompt_embeds], dim=0)
+        else:
+            ctx = prompt_embeds
+        st = {"B": B, "Bc": ctx.shape[0]}
+        st["kv_c"] = self.controlnet.context_kv(ctx.contiguous())
+        st["kv_u"] = self.diffusion.context_kv(ctx.contiguous())
+        st["cond_emb"] = self.controlnet.cond_embedding(cond)  # B images; image n of the CFG batch reads n % B
+        cls = None
+        if acquisition_time is not None:
+            a = acquisition_time.reshape(B).float()
+            cls = (torch.cat([a, a]) if self.cfg else a).reshape(-1, 1).to(cond.device)
+        st["cls"] = cls
+        return st
+
+    @torch.no_grad()
+    def step(self, st, x: torch.Tensor, t, ddpm_noise: Optional[torch.Tensor] = None):
+        """One denoising step on the fp32 latent x (B,C,h,w); returns (x_prev, x0)."""
+        ts = torch.tensor([float(t)], dtype=torch.float32, device=x.device)
+        down, mid = self.controlnet.forward_native(
+            x, ts, None, self.conditioning_scale, class_labels=st["cls"], _ctx_kv=st["kv_c"],
+            _cond_emb=st["cond_emb"], _x_batch=st["Bc"])
+        out = self.diffusion(x, ts, class_labels=st["cls"], down_block_additional_residuals=down,
+                             mid_block_additional_residual=mid, _ctx_kv=st["kv_u"], _x_batch=st["Bc"])
+        if self.cfg:
+            if isinstance(self.scheduler, DDPMScheduler):
+                return self.scheduler.step_cfg(out, t, x, self.guidance_scale, noise=ddpm_noise)
+            return self.scheduler.step_cfg(out, t, x, self.guidance_scale)
+        if isinstance(self.scheduler, DDPMScheduler):
+            return self.scheduler.step(out, t, x, noise=ddpm_noise)
+        return self.scheduler.step(out, t, x)
+
+    @torch.no_grad()
+    def sample(self, noise: torch.Tensor, cond: torch.Tensor, prompt_embeds: torch.Tensor,
+               empty_prompt_embeds: torch.Tensor, acquisition_time: Optional[torch.Tensor] = None,
+               ddpm_noise: Optional[List[torch.Tensor]] = None, record_latents: bool = False,
+               max_steps: Optional[int] = None, decode: bool = True):
+        st = self.prepare(cond, prompt_embeds, empty_prompt_embeds, acquisition_time)
+        x = noise.float().contiguous()
+        trace = []
+        for i, t in enumerate(self.scheduler.timesteps):
+            if max_steps is not None and i >= max_steps:
+                break
+            x, _ = self.step(st, x, int(t), None if ddpm_noise is None else ddpm_noise[i])
+            if record_latents:
+                trace.append(x.clone())
+        res = {"latent": x}
+        if record_latents:
+            res["latents"] = trace
+        if decode and self.stage1 is not None:
+            # run_controlnet_inference.py:255-256
+            res["image"] = self.stage1.decode(x / self.scale_factor)
+        return res
+
+
+def sample(controlnet, diffusion, scheduler, noise, cond, prompt_embeds, empty_prompt_embeds,
+           guidance_scale=None, conditioning_scale=1.0, acquisition_time=None, stage1=None, scale_factor=0.01,
+           **kw):
+    """Functional form of the reference loop for one batch (run_controlnet_inference.py:211-256)."""
+    s = Sampler(controlnet, diffusion, scheduler, stage1, guidance_scale, conditioning_scale, scale_factor)
+    return s.sample(noise, cond, prompt_embeds, empty_prompt_embeds, acquisition_time, **kw)

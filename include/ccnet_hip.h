@@ -146,6 +146,13 @@ int ccnet_cfg_scheduler_step(const float* model_out, int cfg_mode, float guidanc
 int ccnet_nchw_f32_to_nhwc_bf16(const float* x, int N, int C, int HW, void* out, int ldo, void* stream);
 int ccnet_nhwc_bf16_to_nchw_f32(const void* x, int ldx, int N, int C, int HW, float* out, void* stream);
 
+/* AEKL 1x1 convs on <= 8 fp32 NCHW channels: quant_conv_mu / post_quant_conv (mode 0) and
+ * z_sigma = exp(clamp(quant_conv_log_sigma(h), -30, 20) / 2) (mode 1); out = a + b*c is AutoencoderKL.sampling
+ * (util.py:1490-1491). */
+int ccnet_pointwise_nchw_f32(const float* x, int N, int Cin, int HW, const float* w /*[Cout][Cin]*/,
+                             const float* bias, int Cout, int mode, float* out, void* stream);
+int ccnet_axpy_f32(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
+
 /* clip((x+1)/2,0,1) -> rint(*255) -> uint8 of channel 0 (util.py:1162-1173,1412-1416). x fp32 NCHW. */
 int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
 
