@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the ccnet hot path on MI355X: 512^2 images/s for 50 DDIM steps with CFG through
+ControlNet + UNet (SD-2.1-base geometry, monai-generative kwargs) + AEKL decode.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run, one rank per
+GPU).  One "step" = one pass of the hot path over one batch: `--batch` images (default 16, BASELINE.json configs[1])
+x (prepare + 50 denoising steps with CFG + AEKL decode + uint8 map).  Inputs are synthetic, seed-indexed and already
+resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant kernel (implicit-GEMM conv/linear on bf16 MFMA): algorithmic FLOPs of every launch in
+                  the timed region / summed HIP-event durations of those launches (events recorded by the library on
+                  the launch stream), against the 2.5 PFLOP/s dense bf16 peak.
+  cpu_baseline -- the fp32 oracle (oracle/, a CPU restatement of the reference path) timed on this box's host cores
+                  on a bounded sample (batch 1, CFG, a few denoising steps + one AEKL decode), extrapolated to 50 steps.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+G1 = dict(spatial_dims=2, in_channels=4, num_res_blocks=2, num_channels=[320, 640, 1280, 1280],
+          attention_levels=[True, True, True, False], with_conditioning=True, cross_attention_dim=1024,
+          num_head_channels=64, norm_eps=1e-5)
+G1_CE = dict(conditioning_embedding_in_channels=1, conditioning_embedding_num_channels=[64, 128, 128, 256])
+STAGE1 = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[128, 256, 256, 512], latent_channels=4,
+              num_res_blocks=2, attention_levels=[False] * 4, with_encoder_nonlocal_attn=False,
+              with_decoder_nonlocal_attn=False)
+SCHED = dict(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0205, schedule="scaled_linear_beta",
+             prediction_type="v_prediction")
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def build_models(dev, acq: bool):
+    import ccnet_amd.nets as pn
+    from ccnet_amd.synthetic import init_weights
+    cn = pn.ControlNet(**G1, **G1_CE)
+    un = pn.DiffusionModelUNet(out_channels=4, **G1)
+    vae = pn.AutoencoderKL(**STAGE1)
+    if acq:
+        pn.adjust_class_embedding(cn)
+        pn.adjust_class_embedding(un)
+    cn, un, vae = cn.to(dev), un.to(dev), vae.to(dev)
+    init_weights(cn, 101, device=dev)
+    init_weights(un, 102, device=dev)
+    init_weights(vae, 103, device=dev)
+    return cn.eval(), un.eval(), vae.eval()
+
+
+def cpu_baseline(steps_sample: int, acq: bool):
+    """Oracle on the host cores: batch 1, CFG (effective batch 2), `steps_sample` denoising steps + one decode."""
+    import oracle.nets as on
+    import oracle.schedulers as osch
+    from oracle.sampler import sample as osample
+    from ccnet_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    with torch.device("meta"):
+        cn = on.ControlNet(**G1, **G1_CE)
+        un = on.DiffusionModelUNet(out_channels=4, **G1)
+        vae = on.AutoencoderKL(**STAGE1)
+        if acq:
+            on.adjust_class_embedding(cn)
+            on.adjust_class_embedding(un)
+    for m in (cn, un, vae):
+        m.to_empty(device="cpu")
+        for p in m.parameters():  # cheap finite fill; values do not affect the timing
+            p.data.uniform_(-0.02, 0.02)
+        m.eval()
+    b = make_batch([0], seed=42, acq=acq)
+    sch = osch.DDIMScheduler(clip_sample=False, **SCHED)
+    sch.set_timesteps(50)
+    kw = dict(guidance_scale=7.0, conditioning_scale=1.0, acquisition_time=b.get("acquisition_time"))
+    t0 = time.perf_counter()
+    r = osample(cn, un, sch, b["noise"], b["cond"], b["prompt_embeds"], b["empty_prompt_embeds"],
+                max_steps=steps_sample, **kw)
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        vae.decode(r["latent"] / 0.1)
+    t2 = time.perf_counter()
+    per_step, dec = (t1 - t0) / steps_sample, (t2 - t1)
+    total = 50 * per_step + dec
+    return {"value": 1.0 / total, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"batch 1 CFG, {steps_sample} of 50 DDIM steps ({per_step:.2f} s/step) + 1 AEKL decode "
+                      f"({dec:.2f} s), extrapolated linearly to 50 steps; fp32 torch CPU ops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ccnet_amd import ops
+    from ccnet_amd.sampling import Sampler, to_uint8
+    from ccnet_amd.schedulers import DDIMScheduler
+    from ccnet_amd.synthetic import make_batch
+
+    acq = True
+    cn, un, vae = build_models(dev, acq)
+    sch = DDIMScheduler(clip_sample=False, **SCHED)
+    sch.set_timesteps(args.ddim_steps)
+    sampler = Sampler(cn, un, sch, vae, guidance_scale=7.0, conditioning_scale=1.0, scale_factor=0.1)
+
+    B = args.batch
+    nb = args.warmup + args.steps
+    # seed-indexed shards: rank r owns the contiguous index block [r*nb*B, (r+1)*nb*B)
+    batches = []
+    for k in range(nb):
+        idx = [rank * nb * B + k * B + i for i in range(B)]
+        b = make_batch(idx, seed=42, acq=acq)
+        batches.append({k2: v.to(dev) for k2, v in b.items()})
+
+    def one_pass(b):
+        r = sampler.sample(b["noise"], b["cond"], b["prompt_embeds"], b["empty_prompt_embeds"],
+                           b.get("acquisition_time"))
+        u8 = to_uint8(r["image"])
+        if dist is not None:  # gather generated latents + slices for downstream FRD/FID (one exchange per batch)
+            lat = torch.empty((world,) + tuple(r["latent"].shape), dtype=r["latent"].dtype, device=dev)
+            img = torch.empty((world,) + tuple(u8.shape), dtype=u8.dtype, device=dev)
+            dist.all_gather_into_tensor(lat, r["latent"].contiguous())
+            dist.all_gather_into_tensor(img, u8.contiguous())
+            return lat, img
+        return r["latent"], u8
+
+    prof = not args.no_prof
+    ops.prof_enable(prof)
+    for k in range(args.warmup):
+        one_pass(batches[k])
+        if prof:
+            ops.prof_collect()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, nb):
+        one_pass(batches[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = None
+    if prof:
+        ms, flops, launches = ops.prof_collect()
+        ops.prof_enable(False)
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA)",
+                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": int(launches),
+                "kernel_ms_total": round(ms, 3), "share_of_wall": round(ms * 1e-3 / dt, 4)}
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        images = B * world * args.steps
+        out = {
+            "metric": "512^2 images/sec (50 DDIM steps, CFG, ControlNet+UNet+AEKL)", "value": round(images / dt, 4),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: ControlNet+LDM DDIM {args.ddim_steps}-step sampling with CFG, "
+                                   f"batch {B} per GPU (CFG batch {2 * B}), 512^2 slices (64x64x4 latent), SD-2.1-base "
+                                   "geometry + acq-time MLP + stage1 AEKL decode; seeded random weights",
+                       "batch_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": 7.0,
+                       "sharding": f"seed-indexed contiguous blocks over {world} rank(s), all_gather of latents+uint8"},
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps, acq)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,17 +112,22 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int ldx
 }
 
 // ------------------------------------------------------------------ edge convolutions
-// conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16; thread = (pixel, 8 couts).
+// conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16; thread = (pixel, 8 couts); blockIdx.y = chunk of <= 256 couts
+// whose weights sit in LDS.
+constexpr int CIS_CHUNK = 256;
 __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int Nsrc, int N, int Cin, int H, int W,
                                                             const float* w, const float* bias, int Cout, int stride,
                                                             int act, const __bf16* res, int Nres, int ldres,
                                                             __bf16* out, int ldo, int Hout, int Wout) {
-    extern __shared__ float sw[];  // [Cout][Cin*9] + bias[Cout]
+    extern __shared__ float sw[];  // [chunk couts][Cin*9] + bias[chunk couts]
     const int K = Cin * 9;
-    for (int i = threadIdx.x; i < Cout * K; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < Cout; i += 256) sw[Cout * K + i] = bias ? bias[i] : 0.f;
+    const int c_base = blockIdx.y * CIS_CHUNK;
+    const int c_cnt = min(CIS_CHUNK, ldo - c_base);            // channels of the padded row this block writes
+    const int c_real = max(0, min(c_cnt, Cout - c_base));      // of which real output channels
+    for (int i = threadIdx.x; i < c_real * K; i += 256) sw[i] = w[(long long)c_base * K + i];
+    for (int i = threadIdx.x; i < c_real; i += 256) sw[CIS_CHUNK * K + i] = bias ? bias[c_base + i] : 0.f;
     __syncthreads();
-    const int cg = (ldo) / 8;  // write every 8-channel group of the padded row (zeros beyond Cout)
+    const int cg = c_cnt / 8;
     const long long total = (long long)N * Hout * Wout * cg;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int g = (int)(idx % cg);
@@ -131,38 +136,39 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (g * 8 < Cout) {
-            float xin[72];
+        if (g * 8 < c_real) {
             const float* xb = x + (long long)(n % Nsrc) * Cin * H * W;
-            for (int c = 0; c < Cin; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (g * 8 + e < c_real) v[e] = sw[CIS_CHUNK * K + g * 8 + e];
+            for (int c = 0; c < Cin; ++c) {
 #pragma unroll
                 for (int kr = 0; kr < 3; ++kr)
 #pragma unroll
                     for (int ks = 0; ks < 3; ++ks) {
                         const int iy = oy * stride - 1 + kr, ix = ox * stride - 1 + ks;
-                        xin[c * 9 + kr * 3 + ks] =
-                            ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xb[((long long)c * H + iy) * W + ix] : 0.f;
-                    }
+                        const float xv = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                                             ? xb[((long long)c * H + iy) * W + ix] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int co = g * 8 + e;
-                if (co < Cout) {
-                    float s = sw[Cout * K + co];
-                    const float* wr = sw + co * K;
-                    for (int k = 0; k < K; ++k) s += wr[k] * xin[k];
-                    v[e] = act == 1 ? silu_f(s) : s;
-                }
+                        for (int e = 0; e < 8; ++e)
+                            if (g * 8 + e < c_real) v[e] += sw[(g * 8 + e) * K + c * 9 + kr * 3 + ks] * xv;
+                    }
+            }
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (g * 8 + e < c_real) v[e] = silu_f(v[e]);
             }
             if (res) {
                 float r[8];
                 const long long rpix = ((long long)(n % Nres) * Hout + oy) * Wout + ox;
-                unpack8(*(const u32x4*)(res + rpix * ldres + g * 8), r);
+                unpack8(*(const u32x4*)(res + rpix * ldres + c_base + g * 8), r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (g * 8 + e < Cout) v[e] += r[e];
+                    if (g * 8 + e < c_real) v[e] += r[e];
             }
         }
-        *(u32x4*)(out + pixel * ldo + g * 8) = pack8(v);
+        *(u32x4*)(out + pixel * ldo + c_base + g * 8) = pack8(v);
     }
 }
 
@@ -346,10 +352,17 @@ extern "C" int ccnet_conv_in_small(const float* x, int Nsrc, int N, int Cin, int
     if (stride != 1 && stride != 2) return CCNET_EUNSUP;
     if (res && (Nres <= 0 || (ldres % 8))) return CCNET_EINVAL;
     if (Hout != (H + 2 - 3) / stride + 1 || Wout != (W + 2 - 3) / stride + 1) return CCNET_EINVAL;
-    const size_t lds = (size_t)(Cout * Cin * 9 + Cout) * sizeof(float);
-    if (lds > 60000) return CCNET_EUNSUP;
-    const long long total = (long long)N * Hout * Wout * (ldo / 8);
-    hipLaunchKernelGGL(conv_in_small_kernel, dim3(grid_for(total, 256)), dim3(256), lds, (hipStream_t)stream, x, Nsrc,
+    const size_t lds = (size_t)(CIS_CHUNK * Cin * 9 + CIS_CHUNK) * sizeof(float);  // <= 74 KB at Cin = 8
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_in_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)(CIS_CHUNK * 8 * 9 + CIS_CHUNK) * sizeof(float))) != hipSuccess)
+            return CCNET_ELAUNCH;
+        attr_set = true;
+    }
+    const int ychunks = (ldo + CIS_CHUNK - 1) / CIS_CHUNK;
+    const long long total = (long long)N * Hout * Wout * ((ldo < CIS_CHUNK ? ldo : CIS_CHUNK) / 8);
+    hipLaunchKernelGGL(conv_in_small_kernel, dim3(grid_for(total, 256), ychunks), dim3(256), lds, (hipStream_t)stream, x, Nsrc,
                        N, Cin, H, W, w, bias, Cout, stride, act, (const __bf16*)res, Nres, ldres, (__bf16*)out, ldo,
                        Hout, Wout);
     CCNET_LAUNCH_CHECK();

@@ -819,14 +819,30 @@ class AutoencoderKL(nn.Module):
             raise CcnetError("ccnet_amd.AutoencoderKL runs on the GPU only (no CPU fallback)")
         z = z.contiguous().float()
         zq = ops.pointwise_nchw(z, pk["post_quant_conv"][0], pk["post_quant_conv"][1], 0)
-        return self._run(pk["decoder"], zq)
+        up = 2 ** (len(self.num_channels) - 1)
+        chunk = self._batch_chunk(z.shape[2] * up, z.shape[3] * up)
+        if z.shape[0] <= chunk:
+            return self._run(pk["decoder"], zq)
+        return torch.cat([self._run(pk["decoder"], zq[i:i + chunk].contiguous())
+                          for i in range(0, z.shape[0], chunk)], dim=0)
+
+    def _batch_chunk(self, H: int, W: int) -> int:
+        """Largest image count whose biggest activation stays below the conv kernel's 2 GiB buffer window."""
+        cmax = max(self.num_channels[:2]) if len(self.num_channels) > 1 else self.num_channels[0]
+        return max(1, (2 ** 31 - 2 ** 20) // (cmax * H * W * 2))
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor):
         pk = self._pk or self._pack()
         if not x.is_cuda:
             raise CcnetError("ccnet_amd.AutoencoderKL runs on the GPU only (no CPU fallback)")
-        h = self._run(pk["encoder"], x.contiguous().float())
+        x = x.contiguous().float()
+        chunk = self._batch_chunk(x.shape[2], x.shape[3])
+        if x.shape[0] <= chunk:
+            h = self._run(pk["encoder"], x)
+        else:
+            h = torch.cat([self._run(pk["encoder"], x[i:i + chunk].contiguous())
+                           for i in range(0, x.shape[0], chunk)], dim=0)
         z_mu = ops.pointwise_nchw(h, pk["quant_conv_mu"][0], pk["quant_conv_mu"][1], 0)
         z_sigma = ops.pointwise_nchw(h, pk["quant_conv_log_sigma"][0], pk["quant_conv_log_sigma"][1], 1)
         return z_mu, z_sigma
