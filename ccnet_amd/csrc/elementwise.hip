@@ -113,19 +113,25 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int ldx
 
 // ------------------------------------------------------------------ edge convolutions
 // conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16; thread = (pixel, 8 couts); blockIdx.y = chunk of <= 256 couts
-// whose weights sit in LDS.
+// whose weights sit in LDS k-major ([tap][cout]) so the 8 weights a lane needs per tap are two ds_read_b128 and
+// consecutive lanes (consecutive cout groups) hit consecutive banks.
 constexpr int CIS_CHUNK = 256;
-__global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int Nsrc, int N, int Cin, int H, int W,
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int Nsrc, int N, int H, int W,
                                                             const float* w, const float* bias, int Cout, int stride,
                                                             int act, const __bf16* res, int Nres, int ldres,
                                                             __bf16* out, int ldo, int Hout, int Wout) {
-    extern __shared__ float sw[];  // [chunk couts][Cin*9] + bias[chunk couts]
-    const int K = Cin * 9;
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][CIS_CHUNK] + bias[CIS_CHUNK]
+    constexpr int K = CIN * 9;
     const int c_base = blockIdx.y * CIS_CHUNK;
     const int c_cnt = min(CIS_CHUNK, ldo - c_base);            // channels of the padded row this block writes
     const int c_real = max(0, min(c_cnt, Cout - c_base));      // of which real output channels
-    for (int i = threadIdx.x; i < c_real * K; i += 256) sw[i] = w[(long long)c_base * K + i];
-    for (int i = threadIdx.x; i < c_real; i += 256) sw[CIS_CHUNK * K + i] = bias ? bias[c_base + i] : 0.f;
+    for (int i = threadIdx.x; i < (K + 1) * CIS_CHUNK; i += 256) {
+        const int k = i / CIS_CHUNK, c = i % CIS_CHUNK;
+        float v = 0.f;
+        if (c < c_real) v = k < K ? w[(long long)(c_base + c) * K + k] : (bias ? bias[c_base + c] : 0.f);
+        sw[i] = v;
+    }
     __syncthreads();
     const int cg = c_cnt / 8;
     const long long total = (long long)N * Hout * Wout * cg;
@@ -133,43 +139,63 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int 
         const int g = (int)(idx % cg);
         const long long pixel = idx / cg;
         const int ox = (int)(pixel % Wout), oy = (int)((pixel / Wout) % Hout), n = (int)(pixel / ((long long)Wout * Hout));
+        const float* xb = x + (long long)(n % Nsrc) * CIN * H * W;
         float v[8];
+        {
+            const f32x4 b0 = *(const f32x4*)(sw + K * CIS_CHUNK + g * 8), b1 = *(const f32x4*)(sw + K * CIS_CHUNK + g * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        if (g * 8 < c_real) {
-            const float* xb = x + (long long)(n % Nsrc) * Cin * H * W;
+            for (int e = 0; e < 4; ++e) { v[e] = b0[e]; v[4 + e] = b1[e]; }
+        }
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int kr = 0; kr < 3; ++kr)
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int iy = oy * stride - 1 + kr, ix = ox * stride - 1 + ks;
+                    const float xv = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                                         ? xb[((long long)c * H + iy) * W + ix] : 0.f;
+                    const float* wr = sw + (c * 9 + kr * 3 + ks) * CIS_CHUNK + g * 8;
+                    const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += w0[e] * xv; v[4 + e] += w1[e] * xv; }
+                }
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);  // silu(0) = 0 keeps the padded channels zero
+        }
+        if (res && g * 8 < c_real) {
+            float r[8];
+            const long long rpix = ((long long)(n % Nres) * Hout + oy) * Wout + ox;
+            unpack8(*(const u32x4*)(res + rpix * ldres + c_base + g * 8), r);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (g * 8 + e < c_real) v[e] = sw[CIS_CHUNK * K + g * 8 + e];
-            for (int c = 0; c < Cin; ++c) {
-#pragma unroll
-                for (int kr = 0; kr < 3; ++kr)
-#pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) {
-                        const int iy = oy * stride - 1 + kr, ix = ox * stride - 1 + ks;
-                        const float xv = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                                             ? xb[((long long)c * H + iy) * W + ix] : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (g * 8 + e < c_real) v[e] += sw[(g * 8 + e) * K + c * 9 + kr * 3 + ks] * xv;
-                    }
-            }
-            if (act == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (g * 8 + e < c_real) v[e] = silu_f(v[e]);
-            }
-            if (res) {
-                float r[8];
-                const long long rpix = ((long long)(n % Nres) * Hout + oy) * Wout + ox;
-                unpack8(*(const u32x4*)(res + rpix * ldres + c_base + g * 8), r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (g * 8 + e < c_real) v[e] += r[e];
-            }
+                if (g * 8 + e < c_real) v[e] += r[e];
         }
         *(u32x4*)(out + pixel * ldo + c_base + g * 8) = pack8(v);
     }
+}
+
+template <int CIN>
+int launch_conv_in_small(const float* x, int Nsrc, int N, int H, int W, const float* w, const float* bias, int Cout,
+                         int stride, int act, const void* res, int Nres, int ldres, void* out, int ldo, int Hout,
+                         int Wout, hipStream_t st) {
+    const size_t lds = (size_t)(CIN * 9 + 1) * CIS_CHUNK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_in_small_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return CCNET_ELAUNCH;
+        attr_set = true;
+    }
+    const int ychunks = (ldo + CIS_CHUNK - 1) / CIS_CHUNK;
+    const long long total = (long long)N * Hout * Wout * ((ldo < CIS_CHUNK ? ldo : CIS_CHUNK) / 8);
+    long long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(conv_in_small_kernel<CIN>, dim3((int)g, ychunks), dim3(256), lds, st, x, Nsrc, N, H, W, w, bias,
+                       Cout, stride, act, (const __bf16*)res, Nres, ldres, (__bf16*)out, ldo, Hout, Wout);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
 }
 
 // conv_out_small: NHWC bf16 -> fp32 NCHW, Cout <= 8, 3x3 stride 1 pad 1; one wave per output pixel.
@@ -352,21 +378,19 @@ extern "C" int ccnet_conv_in_small(const float* x, int Nsrc, int N, int Cin, int
     if (stride != 1 && stride != 2) return CCNET_EUNSUP;
     if (res && (Nres <= 0 || (ldres % 8))) return CCNET_EINVAL;
     if (Hout != (H + 2 - 3) / stride + 1 || Wout != (W + 2 - 3) / stride + 1) return CCNET_EINVAL;
-    const size_t lds = (size_t)(CIS_CHUNK * Cin * 9 + CIS_CHUNK) * sizeof(float);  // <= 74 KB at Cin = 8
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_in_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)(CIS_CHUNK * 8 * 9 + CIS_CHUNK) * sizeof(float))) != hipSuccess)
-            return CCNET_ELAUNCH;
-        attr_set = true;
+    hipStream_t st = (hipStream_t)stream;
+#define CIS_ARGS x, Nsrc, N, H, W, w, bias, Cout, stride, act, res, Nres, ldres, out, ldo, Hout, Wout, st
+    switch (Cin) {
+        case 1: return launch_conv_in_small<1>(CIS_ARGS);
+        case 2: return launch_conv_in_small<2>(CIS_ARGS);
+        case 3: return launch_conv_in_small<3>(CIS_ARGS);
+        case 4: return launch_conv_in_small<4>(CIS_ARGS);
+        case 5: return launch_conv_in_small<5>(CIS_ARGS);
+        case 6: return launch_conv_in_small<6>(CIS_ARGS);
+        case 7: return launch_conv_in_small<7>(CIS_ARGS);
+        default: return launch_conv_in_small<8>(CIS_ARGS);
     }
-    const int ychunks = (ldo + CIS_CHUNK - 1) / CIS_CHUNK;
-    const long long total = (long long)N * Hout * Wout * ((ldo < CIS_CHUNK ? ldo : CIS_CHUNK) / 8);
-    hipLaunchKernelGGL(conv_in_small_kernel, dim3(grid_for(total, 256), ychunks), dim3(256), lds, (hipStream_t)stream, x, Nsrc,
-                       N, Cin, H, W, w, bias, Cout, stride, act, (const __bf16*)res, Nres, ldres, (__bf16*)out, ldo,
-                       Hout, Wout);
-    CCNET_LAUNCH_CHECK();
-    return CCNET_OK;
+#undef CIS_ARGS
 }
 
 extern "C" int ccnet_conv_out_small(const void* x, int ldx, int N, int H, int W, int Cin, const void* w,

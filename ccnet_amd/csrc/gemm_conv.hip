@@ -2,19 +2,21 @@
 //
 // Data layout in HBM: activations NHWC bf16 (a "pixel row" of C channels is contiguous), weights
 // [Cout][R*R*Cin] bf16 with K ordered (kr, ks, cin) so a 64-channel K-slice of one filter tap is one
-// contiguous 128-byte run for both operands.  One workgroup computes a (64*WM pixels) x (64*WN couts)
-// tile; every wave owns a 64x64 sub-tile = 2x2 accumulators of v_mfma_f32_32x32x16_bf16 with the
-// weights as the A operand (rows = cout) and the pixels as the B operand (cols = pixel), so that each
-// lane ends up with 4 consecutive couts of one pixel per accumulator quad.
+// contiguous 128-byte run for both operands.  One workgroup of WM x WN waves computes a
+// (32*TJ*WM pixels) x (32*TI*WN couts) tile; every wave owns TI x TJ accumulators of
+// v_mfma_f32_32x32x16_bf16 with the weights as the A operand (rows = cout) and the pixels as the B operand
+// (cols = pixel), so each lane ends up with 4 consecutive couts of one pixel per accumulator quad.
 //
-// K loop: one step = 64 channels of one tap.  Operand tiles are fetched with raw buffer loads (the
-// hardware range check returns 0 for the padding taps and for rows beyond M / Cout, so the gather has no
-// branches), written to LDS in an XOR-swizzled [row][64] image (conflict-free ds_read_b128 fragment
-// reads) and double-buffered: the loads of step k+1 are issued before the MFMAs of step k and written
-// after them, one barrier per step.
+// K loop: one step = 64 channels of one tap.  Operand tiles go HBM/L2 -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write); the buffer range check returns 0 for the
+// padding taps and for rows beyond M / Cout, so the gather has no branches.  The LDS image of a tile is
+// [row][64] bf16 with the 16-B chunk index XOR-swizzled by ((row >> 1) & 7) -- applied on the SOURCE address,
+// because a DMA lands at wave-base + lane*16 -- which makes the ds_read_b128 fragment reads conflict-free.
+// Two stages: the DMA of step k+1 is issued in four slices between the MFMA groups of step k and retired by
+// the vmcnt(0) + barrier that ends the step.
 //
 // Epilogue: accumulators go through a per-wave fp32 LDS patch so that bias / time-embedding / residual
-// reads and the bf16 stores are 16 B per lane and 128 B contiguous per pixel row.
+// reads and the bf16 stores are 16 B per lane and contiguous per pixel row.
 #include "common.h"
 #include <vector>
 
@@ -34,16 +36,21 @@ struct ConvArgs {
 
 constexpr unsigned OOB = 0x80000000u;  // beyond any num_records we accept (< 2^31 bytes)
 
-__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+__device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, unsigned voff) {
+    // LDS-DMA: 64 lanes x 16 B land at lds_wave_base + lane*16 (wave-uniform base), no VGPR round trip
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0,
+                                             0, 0);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int TJ, int TI>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs a) {
-    constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
+    constexpr int NT = 64 * WM * WN, BM = 32 * TJ * WM, BN = 32 * TI * WN;
     constexpr int RPP = NT / 8;            // tile rows covered by one pass of all threads (8 x 16 B per row)
     constexpr int NX = BM / RPP, NW = BN / RPP;
+    constexpr int NL = NX + NW;            // DMA instructions per thread per K-step
     constexpr int STAGE = (BM + BN) * 128;  // bytes per pipeline stage
+    constexpr int EPW = 32 * TI + 4;        // epilogue patch row stride in floats
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows per DMA pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,9 +78,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 
     // per-thread gather rows: image index and top-left input coordinate of each output pixel
     int xn[NX], xiy0[NX], xix0[NX];
+    unsigned xsw[NX], woff[NW];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const int m = m0 + lrow + i * RPP;
+        const int r = lrow + i * RPP, m = m0 + r;
         if (m < a.M) {
             const int n = m / a.HWout, rem = m - n * a.HWout;
             const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
@@ -81,12 +89,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         } else {
             xn[i] = -1; xiy0[i] = 0; xix0[i] = 0;
         }
+        xsw[i] = (unsigned)((lchunk ^ ((r >> 1) & 7)) << 3);
     }
-    unsigned woff[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int n = n0 + lrow + i * RPP;
-        woff[i] = n < a.Cout ? (unsigned)(n * a.ldw + lchunk * 8) * 2u : OOB;
+        const int r = lrow + i * RPP, n = n0 + r;
+        woff[i] = n < a.Cout ? (unsigned)(n * a.ldw + ((lchunk ^ ((r >> 1) & 7)) << 3)) * 2u : OOB;
     }
     const int Hl = a.Hin * a.ups, Wl = a.Win * a.ups, ush = a.ups >> 1;
 
@@ -101,116 +109,104 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         }
     };
 
-    u32x4 xr[NX], wr[NW];
-    int tap_n = 0, cc_n = 0, kt_n = 0;  // K-step that the next issue_loads() fetches
-    auto issue_loads = [&]() {
-        if (cc_n == 0) set_tap(tap_n);
-        if (cc_n < a.CT1) {
-            const unsigned co = (unsigned)(cc_n * 64 + lchunk * 8);
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-                xr[i] = buf_load16(r1, pix[i] < 0 ? OOB : ((unsigned)pix[i] * (unsigned)a.ldx1 + co) * 2u);
-        } else {
-            const unsigned co = (unsigned)((cc_n - a.CT1) * 64 + lchunk * 8);
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-                xr[i] = buf_load16(r2, pix[i] < 0 ? OOB : ((unsigned)pix[i] * (unsigned)a.ldx2 + co) * 2u);
-        }
+    // K-step being fetched: (tap_n, cc_n) and its flat index kt_n; slices [lo, hi) of its NL DMA instructions
+    int tap_n = 0, cc_n = 0, kt_n = 0;
+    auto issue_slice = [&](int s, int lo, int hi) {
+        char* xb = smem + s * STAGE + wave * 1024;
+        char* wb = xb + BM * 128;
+        const bool src2 = cc_n >= a.CT1;
+        const unsigned co = (unsigned)((src2 ? cc_n - a.CT1 : cc_n) * 64);
+        const unsigned ld = (unsigned)(src2 ? a.ldx2 : a.ldx1);
         const unsigned kb = (unsigned)kt_n * 128u;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) wr[i] = buf_load16(rw, woff[i] == OOB ? OOB : woff[i] + kb);
+        for (int l = 0; l < NL; ++l) {
+            if (l < lo || l >= hi) continue;
+            if (l < NX) {
+                const unsigned vo = pix[l] < 0 ? OOB : ((unsigned)pix[l] * ld + co + xsw[l]) * 2u;
+                if (!src2) buf_dma16(r1, xb + l * RPP * 128, vo);
+                else buf_dma16(r2, xb + l * RPP * 128, vo);
+            } else {
+                const int i = l - NX;
+                buf_dma16(rw, wb + i * RPP * 128, woff[i] == OOB ? OOB : woff[i] + kb);
+            }
+        }
+    };
+    auto advance = [&]() {
         ++kt_n;
         if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
     };
-    auto store_stage = [&](int s) {
-        char* xb = smem + s * STAGE;
-        char* wb = xb + BM * 128;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int r = lrow + i * RPP;
-            *(u32x4*)(xb + r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4)) = xr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int r = lrow + i * RPP;
-            *(u32x4*)(wb + r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4)) = wr[i];
-        }
-    };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int swz = (l31 >> 1) & 7;
-    const int xrow_off = (wm * 64 + l31) * 128, wrow_off = (wn * 64 + l31) * 128;
-    auto compute = [&](int s) {
-        const char* xb = smem + s * STAGE;
-        const char* wb = xb + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int co = ((2 * ks + hh) ^ swz) << 4;
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * 128 + co);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * 128 + co);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    };
+    const int xrow_off = (wm * 32 * TJ + l31) * 128, wrow_off = (wn * 32 * TI + l31) * 128;
 
-    issue_loads();
-    store_stage(0);
+    set_tap(0);
+    issue_slice(0, 0, NL);
+    advance();
     __syncthreads();
     for (int kt = 0; kt < a.KT; ++kt) {
         const bool more = kt + 1 < a.KT;
-        if (more) issue_loads();
-        compute(kt & 1);
-        if (more) store_stage((kt + 1) & 1);
-        __syncthreads();
+        const int s = kt & 1;
+        const char* xb = smem + s * STAGE;
+        const char* wb = xb + BM * 128;
+        if (more && cc_n == 0) set_tap(tap_n);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int co = ((2 * ks + hh) ^ swz) << 4;
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * 128 + co);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * 128 + co);
+            if (more) issue_slice(s ^ 1, (NL * ks) / 4, (NL * (ks + 1)) / 4);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) advance();
+        __syncthreads();  // carries the s_waitcnt vmcnt(0) that retires the DMA of the next stage
     }
 
     // ---------------------------------------------------------------- epilogue
-    float* ep = (float*)smem + wave * (32 * 68);
-    const int lr = lane >> 3, lc = lane & 7;
-    const int ncol = n0 + wn * 64 + lc * 8;
-    const bool nok = ncol < a.Cout;
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (a.bias && nok) {
-        const f32x4 b0 = *(const f32x4*)(a.bias + ncol), b1 = *(const f32x4*)(a.bias + ncol + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
-    }
+    float* ep = (float*)smem + wave * (32 * EPW);
     __bf16* outp = a.out + (long long)z * a.so;
+    constexpr int CPR = 4 * TI;  // 8-float chunks per patch row
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TJ; ++j) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                *(f32x4*)(ep + l31 * 68 + i * 32 + 8 * q + 4 * hh) = v;
+                *(f32x4*)(ep + l31 * EPW + i * 32 + 8 * q + 4 * hh) = v;
             }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = rr * 8 + lr;
-            const int m = m0 + wm * 64 + j * 32 + row;
-            const f32x4 v0 = *(const f32x4*)(ep + row * 68 + lc * 8);
-            const f32x4 v1 = *(const f32x4*)(ep + row * 68 + lc * 8 + 4);
-            if (m < a.M && nok) {
+        for (int it = 0; it < 2 * TI; ++it) {
+            const int idx = lane + 64 * it;
+            const int row = idx / CPR, lc = idx - row * CPR;
+            const int m = m0 + wm * 32 * TJ + j * 32 + row;
+            const int ncol = n0 + wn * 32 * TI + lc * 8;
+            const f32x4 v0 = *(const f32x4*)(ep + row * EPW + lc * 8);
+            const f32x4 v1 = *(const f32x4*)(ep + row * EPW + lc * 8 + 4);
+            if (m < a.M && ncol < a.Cout) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias8[e]; v[4 + e] = v1[e] + bias8[4 + e]; }
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                if (a.bias) {
+                    const f32x4 b0 = *(const f32x4*)(a.bias + ncol), b1 = *(const f32x4*)(a.bias + ncol + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
                 if (a.rowvec) {
                     const float* rv = a.rowvec + (long long)(m / a.HWout) * a.ld_rowvec + ncol;
                     const f32x4 t0 = *(const f32x4*)rv, t1 = *(const f32x4*)(rv + 4);
@@ -249,26 +245,70 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 
-template <int WM, int WN>
+int g_force_cfg = -1;  // tuning: force a tile configuration (index into the dispatch below)
+int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, bit1 = w descriptor empty
+
+template <int WM, int WN, int TJ, int TI>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
+    constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EP = (NT / 64) * 32 * (32 * TI + 4) * 4;
+    constexpr int LDS = LDS_MAIN > LDS_EP ? LDS_MAIN : LDS_EP;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set = true;
     }
     ConvArgs b = a;
     b.tilesN = (a.Cout + BN - 1) / BN;
     b.tiles = ((a.M + BM - 1) / BM) * b.tilesN;
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN>), dim3(b.tiles, 1, batch), dim3(NT), LDS, st, b);
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI>), dim3(b.tiles, 1, batch), dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }
 
+struct TileCfg { int bm, bn; int (*fn)(const ConvArgs&, int, hipStream_t); };
+const TileCfg kCfgs[] = {
+    {128, 128, launch<2, 2, 2, 2>},   // 0
+    {128, 64, launch<2, 1, 2, 2>},    // 1
+    {64, 64, launch<1, 1, 2, 2>},     // 2
+    {128, 320, launch<2, 2, 2, 5>},   // 3: Cout = 320 without tile waste
+    {128, 256, launch<2, 2, 2, 4>},   // 4
+    {256, 128, launch<2, 2, 4, 2>},   // 5
+    {256, 256, launch<2, 2, 4, 4>},   // 6
+    {64, 128, launch<1, 2, 2, 2>},    // 7
+    {64, 256, launch<1, 2, 2, 4>},    // 8
+    {256, 64, launch<4, 1, 2, 2>},    // 9
+    {256, 256, launch<4, 2, 2, 4>},   // 10: 8 waves
+    {256, 128, launch<4, 2, 2, 2>},   // 11: 8 waves
+    {128, 160, launch<2, 1, 2, 5>},   // 12: 2 waves
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+int pick_cfg(int M, int Cout, int K, int batch) {
+    if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs) return g_force_cfg;
+    auto blocks = [&](int c) {
+        return (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((Cout + kCfgs[c].bn - 1) / kCfgs[c].bn) * batch;
+    };
+    // measured on MI355X at CFG batch 32 (tools/bench_conv.py): the 128x320 tile (64 px x 160 cout per wave) wins
+    // wherever Cout is a multiple of 320 and K is deep enough to amortise its epilogue; 256x256 wins on very wide
+    // layers (GEGLU linear1) and the 256-channel VAE level; 128x128 elsewhere.
+    const bool n128 = (Cout % 128) == 0 || Cout >= 512;
+    if ((Cout % 320) == 0 && K >= 1280 && blocks(3) >= 128) return 3;
+    if ((Cout % 256) == 0 && (Cout >= 4096 || Cout == 256) && blocks(6) >= 256) return 6;
+    if (n128 && blocks(0) >= 160) return 0;
+    if (blocks(1) >= 384) return 1;
+    return 2;
+}
+
 }  // namespace
+
+extern "C" int ccnet_set_option(int key, int value) {
+    if (key == 0) { g_force_cfg = value; return CCNET_OK; }  // force conv tile configuration (-1 = heuristic)
+    if (key == 1) { g_dbg_zero = value; return CCNET_OK; }
+    return CCNET_EINVAL;
+}
 
 extern "C" int ccnet_prof_enable(int on) {
     g_prof_on = on != 0;
@@ -329,6 +369,8 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     const long long wb = ((long long)p->Cout - 1) * p->ldw * 2 + (long long)a.KT * 128;
     if (xb1 >= 0x7fffffffLL || xb2 >= 0x7fffffffLL || wb >= 0x7fffffffLL) return CCNET_EUNSUP;
     a.x1_bytes = (unsigned)xb1; a.x2_bytes = (unsigned)xb2; a.w_bytes = (unsigned)wb;
+    if (g_dbg_zero & 1) { a.x1_bytes = 0; a.x2_bytes = 0; }
+    if (g_dbg_zero & 2) a.w_bytes = 0;
 
     hipStream_t st = (hipStream_t)stream;
     ProfRec* rec = nullptr;
@@ -340,19 +382,9 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
         }
         rec = &g_prof[g_prof_used++];
         rec->flops = 2.0 * a.M * (double)p->Cout * (double)(a.KT * 64) * batch;
-        hipEventRecord(rec->e0, st);
+        (void)hipEventRecord(rec->e0, st);
     }
-    // tile choice: 128x128 when Cout fills it, else 64-wide cout tiles; small problems take smaller
-    // pixel tiles so the grid still covers the 256 CUs.
-    int rc;
-    const long long t22 = (long long)((a.M + 127) / 128) * ((p->Cout + 127) / 128) * batch;
-    const bool n128 = (p->Cout % 128) == 0 || p->Cout >= 512;
-    if (n128 && t22 >= 384)
-        rc = launch<2, 2>(a, batch, st);
-    else if ((long long)((a.M + 127) / 128) * ((p->Cout + 63) / 64) * batch >= 384)
-        rc = launch<2, 1>(a, batch, st);
-    else
-        rc = launch<1, 1>(a, batch, st);
-    if (rec) hipEventRecord(rec->e1, st);
+    const int rc = kCfgs[pick_cfg(a.M, p->Cout, a.KT * 64, batch)].fn(a, batch, st);
+    if (rec) (void)hipEventRecord(rec->e1, st);
     return rc;
 }

@@ -159,6 +159,7 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* str
 /* ------------------------------------------------------------------ profiling hooks for bench.py
  * When enabled, ccnet_conv_gemm_bf16 brackets each launch with hipEvents on `stream`;
  * ccnet_prof_collect synchronises the events and returns summed kernel ms / FLOPs / launches. */
+int ccnet_set_option(int key, int value); /* key 0: conv operand staging, 1 = LDS-DMA (default), 0 = registers */
 int ccnet_prof_enable(int on);
 int ccnet_prof_collect(double* ms, double* flops, int64_t* launches);
 

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv/linear kernel on the G1 (SD-2.1) shapes at CFG batch 32.
+Random data (never zeros: MI355X clocks higher on zero operands), timed with events on the launch stream."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ccnet_amd import ops  # noqa: E402
+from ccnet_amd.ops import Act  # noqa: E402
+
+SHAPES = [
+    # name, N, H, C1, C2, Cout, R, stride, ups
+    ("L0 conv3x3 320->320 @64", 32, 64, 320, 0, 320, 3, 1, 1),
+    ("L0 proj 1x1 320->320 @64", 32, 64, 320, 0, 320, 1, 1, 1),
+    ("L0 qkv 320->960 @64", 32, 64, 320, 0, 960, 1, 1, 1),
+    ("L0 ff1 320->2560 @64", 32, 64, 320, 0, 2560, 1, 1, 1),
+    ("L0 ff2 1280->320 @64", 32, 64, 1280, 0, 320, 1, 1, 1),
+    ("U3 conv3x3 960->320 @64", 32, 64, 640, 320, 320, 3, 1, 1),
+    ("L1 conv3x3 640->640 @32", 32, 32, 640, 0, 640, 3, 1, 1),
+    ("L1 proj 1x1 640->640 @32", 32, 32, 640, 0, 640, 1, 1, 1),
+    ("L1 ff1 640->5120 @32", 32, 32, 640, 0, 5120, 1, 1, 1),
+    ("L1 ff2 2560->640 @32", 32, 32, 2560, 0, 640, 1, 1, 1),
+    ("U2 conv3x3 1920->640 @32", 32, 32, 1280, 640, 640, 3, 1, 1),
+    ("L2 conv3x3 1280->1280 @16", 32, 16, 1280, 0, 1280, 3, 1, 1),
+    ("L2 ff1 1280->10240 @16", 32, 16, 1280, 0, 10240, 1, 1, 1),
+    ("L2 ff2 5120->1280 @16", 32, 16, 5120, 0, 1280, 1, 1, 1),
+    ("U1 conv3x3 2560->1280 @16", 32, 16, 1280, 1280, 1280, 3, 1, 1),
+    ("L3 conv3x3 1280->1280 @8", 32, 8, 1280, 0, 1280, 3, 1, 1),
+    ("U0 conv3x3 2560->1280 @8", 32, 8, 1280, 1280, 1280, 3, 1, 1),
+    ("up conv3x3 1280->1280 8->16", 32, 8, 1280, 0, 1280, 3, 1, 2),
+    ("down conv3x3 s2 320 64->32", 32, 64, 320, 0, 320, 3, 2, 1),
+    ("VAE conv3x3 128->128 @512 N=4", 4, 512, 128, 0, 128, 3, 1, 1),
+    ("VAE conv3x3 256->256 @256 N=8", 8, 256, 256, 0, 256, 3, 1, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--filter", type=str, default="")
+    ap.add_argument("--cfgs", type=str, default="-1", help="comma list of forced tile configs (-1 = heuristic)")
+    ap.add_argument("--dbg-zero", type=int, default=0)
+    args = ap.parse_args()
+    from ccnet_amd import lib as _lib
+    cfgs = [int(c) for c in args.cfgs.split(",")]
+    if args.dbg_zero:
+        from ccnet_amd import lib
+        lib.load().ccnet_set_option(1, args.dbg_zero)
+    dev = torch.device("cuda:0")
+    tot_f, tot_t = 0.0, 0.0
+    for name, N, H, C1, C2, Cout, R, stride, ups in SHAPES:
+        if args.filter and args.filter not in name:
+            continue
+        g = torch.Generator(device=dev).manual_seed(1)
+        x1 = Act(torch.randn(N * H * H, C1, device=dev, generator=g).to(torch.bfloat16), N, H, H, C1)
+        x2 = Act(torch.randn(N * H * H, C2, device=dev, generator=g).to(torch.bfloat16), N, H, H, C2) if C2 else None
+        K = R * R * (C1 + C2)
+        w = (torch.randn(Cout, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        b = torch.randn(Cout, device=dev, generator=g)
+        res = []
+        for cfg in cfgs:
+            _lib.load().ccnet_set_option(0, cfg)
+            try:
+                for _ in range(2):
+                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2)
+            except Exception as e:  # report and keep sweeping
+                print(f"cfg {cfg} failed: {e}", flush=True)
+                res.append((0.0, 1e9))
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            flops = 2.0 * o.rows * Cout * K
+            res.append((flops / ms / 1e9, ms))
+        best = max(range(len(cfgs)), key=lambda i: res[i][0])
+        tot_f += flops
+        tot_t += res[best][1]
+        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c}:{r[0]:6.0f}" for c, r in zip(cfgs, res))
+              + f"  best c{cfgs[best]} {res[best][1] * 1e3:7.1f} us", flush=True)
+    if tot_t:
+        print(f"{'TOTAL of best (equal weight)':34s} {tot_f / tot_t / 1e9:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
