@@ -1,0 +1,301 @@
+"""CPU-side suite (no GPU): the oracle against known-answer constants and the committed golden vectors, the host
+logic of the product (schedulers, state-dict surface, sharding), and the C-ABI library's exported symbols."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _common import SCHED, TINY, TINY_CE, TINY_VAE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "tiny_golden.npz")
+
+
+# ------------------------------------------------------------------ oracle: closed-form / known-answer (Appendix C)
+def test_schedule_constants_appendix_c():
+    import oracle.schedulers as osch
+    s = osch.DDIMScheduler(clip_sample=False, **SCHED)
+    assert abs(s.betas[0].item() - 0.0015) < 1e-9 and abs(s.betas[1].item() - 0.001508110) < 1e-9
+    assert abs(s.betas[999].item() - 0.0205) < 1e-8
+    known = {0: 0.998499990, 1: 0.996994138, 20: 0.967288375, 500: 0.107676789, 960: 0.000212549,
+             980: 0.000142899, 995: 0.000105263, 999: 0.000096911}
+    for t, v in known.items():
+        assert abs(s.alphas_cumprod[t].item() - v) < 5e-9, (t, s.alphas_cumprod[t].item())
+    assert abs(s.alphas_cumprod[999].item() ** 0.5 - 0.00984433) < 1e-7
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(980, -1, -20))
+    s.set_timesteps(200)
+    assert s.timesteps.tolist() == list(range(995, -1, -5))
+
+
+def test_ddim_last_step_returns_x0_and_vpred_algebra():
+    import oracle.schedulers as osch
+    s = osch.DDIMScheduler(clip_sample=False, **SCHED)
+    s.set_timesteps(50)
+    g = torch.Generator().manual_seed(0)
+    x, v = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    prev, x0 = s.step(v, 0, x)
+    assert torch.allclose(prev, x0, atol=1e-6)          # final_alpha_cumprod = 1  =>  x_prev = x0
+    a = s.alphas_cumprod[500]
+    prev, x0 = s.step(v, 500, x)
+    assert torch.allclose(x0, a.sqrt() * x - (1 - a).sqrt() * v, atol=1e-6)
+    eps = a.sqrt() * v + (1 - a).sqrt() * x
+    ap = s.alphas_cumprod[480]
+    assert torch.allclose(prev, ap.sqrt() * x0 + (1 - ap).sqrt() * eps, atol=1e-6)
+    # x0/eps are an orthonormal rotation of (x, v): x = sqrt(a) x0 + sqrt(1-a) eps
+    assert torch.allclose(a.sqrt() * x0 + (1 - a).sqrt() * eps, x, atol=1e-5)
+
+
+def test_ddpm_clip_and_noise_injection():
+    import oracle.schedulers as osch
+    s = osch.DDPMScheduler(**SCHED)
+    assert s.clip_sample is True and s.timesteps.tolist()[:3] == [999, 998, 997]
+    g = torch.Generator().manual_seed(1)
+    x, v, n = (torch.randn(1, 4, 8, 8, generator=g) * 3 for _ in range(3))
+    _, x0 = s.step(v, 700, x, noise=n)
+    assert x0.abs().max() <= 1.0
+    p0, _ = s.step(v, 0, x, noise=n)
+    p0b, _ = s.step(v, 0, x, noise=n * 5)
+    assert torch.equal(p0, p0b)                           # no noise at t = 0
+
+
+def test_cfg_identities():
+    from oracle.sampler import cfg_combine
+    g = torch.Generator().manual_seed(2)
+    out = torch.randn(4, 4, 8, 8, generator=g)
+    u, t = out.chunk(2)
+    assert torch.equal(cfg_combine(out, None), t)
+    assert torch.equal(cfg_combine(out, 0), u)
+    assert torch.allclose(cfg_combine(out, 1.0), t, atol=1e-6)
+    assert torch.allclose(cfg_combine(out, 7.0), u + 7.0 * (t - u))
+
+
+def test_timestep_embedding_cos_first():
+    from oracle.nets import get_timestep_embedding
+    e = get_timestep_embedding(torch.tensor([0, 10]), 8)
+    assert torch.allclose(e[0], torch.tensor([1.0, 1, 1, 1, 0, 0, 0, 0]))
+    assert abs(e[1, 0].item() - math.cos(10.0)) < 1e-6 and abs(e[1, 4].item() - math.sin(10.0)) < 1e-6
+
+
+def test_param_counts_match_published_sd21():
+    """parameter counts of the restated geometry = published SD-2.1 UNet / ControlNet sizes."""
+    import oracle.nets as on
+    from _common import G1, G1_CE
+    with torch.device("meta"):
+        u = on.DiffusionModelUNet(out_channels=4, **G1)
+        c = on.ControlNet(**G1, **G1_CE)
+    nu = sum(p.numel() for p in u.parameters())
+    nc = sum(p.numel() for p in c.parameters())
+    assert abs(nu / 1e6 - 865.9) < 1.0, nu     # SD-2.1 UNet ~ 866 M (without the ccnet class MLP)
+    assert abs(nc / 1e6 - 364.7) < 1.5, nc
+
+
+# ------------------------------------------------------------------ oracle vs committed golden vectors
+def _oracles():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    return make_golden
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return {k: torch.from_numpy(v) for k, v in np.load(GOLD).items()}
+
+
+def test_oracle_reproduces_golden(gold):
+    mg = _oracles()
+    import oracle.schedulers as osch
+    from oracle.sampler import sample as osample, to_uint8
+    cn, un, vae = mg.build_oracles()
+    assert abs(mg.checksum(cn.state_dict()) - gold["ck_cn"].item()) < 1e-3 * gold["ck_cn"].item()
+    assert abs(mg.checksum(un.state_dict()) - gold["ck_un"].item()) < 1e-3 * gold["ck_un"].item()
+    x, ctx, cond, acq = gold["x"], gold["ctx"], gold["cond"], gold["acq"]
+    t = torch.tensor([500])
+    with torch.no_grad():
+        down, mid = cn(x, t, cond, 0.9, ctx, acq.reshape(-1, 1))
+        out = un(x, t, ctx, acq.reshape(-1, 1), down, mid)
+    assert torch.allclose(down[0], gold["cn_down0"], atol=1e-4)
+    assert torch.allclose(mid, gold["cn_mid"], atol=1e-4)
+    assert torch.allclose(out, gold["unet_out"], atol=1e-4)
+    sch = osch.DDIMScheduler(clip_sample=False, **SCHED)
+    sch.set_timesteps(8)
+    res = osample(cn, un, sch, x, cond, ctx, gold["empty"], guidance_scale=3.0, conditioning_scale=1.0,
+                  acquisition_time=acq, stage1=vae, scale_factor=0.5, record_latents=True)
+    assert torch.allclose(torch.stack(res["latents"]), gold["ddim_latents"], atol=2e-4)
+    assert torch.allclose(res["image"], gold["ddim_image"], atol=1e-3)
+    assert np.abs(to_uint8(res["image"]).astype(int) - gold["ddim_u8"].numpy().astype(int)).max() <= 1
+
+
+def test_oracle_invariants_zero_controlnet(gold):
+    """Upstream zero-initialised zero-convs => ControlNet adds nothing; conditioning_scale scales linearly."""
+    mg = _oracles()
+    cn, un, _ = mg.build_oracles()
+    x, ctx, cond, acq = gold["x"], gold["ctx"], gold["cond"], gold["acq"].reshape(-1, 1)
+    t = torch.tensor([500])
+    with torch.no_grad():
+        d1, m1 = cn(x, t, cond, 1.0, ctx, acq)
+        d2, m2 = cn(x, t, cond, 0.5, ctx, acq)
+        assert torch.allclose(m2, 0.5 * m1, atol=1e-6) and torch.allclose(d2[3], 0.5 * d1[3], atol=1e-6)
+        d0, m0 = cn(x, t, cond, 0.0, ctx, acq)
+        assert torch.allclose(un(x, t, ctx, acq, d0, m0), gold["unet_plain"], atol=1e-5)
+
+
+# ------------------------------------------------------------------ product host logic
+def test_product_scheduler_host_constants_match_oracle():
+    import ccnet_amd.schedulers as ps
+    import oracle.schedulers as osch
+    p, o = ps.DDIMScheduler(clip_sample=False, **SCHED), osch.DDIMScheduler(clip_sample=False, **SCHED)
+    assert torch.equal(p.alphas_cumprod, o.alphas_cumprod) and torch.equal(p.betas, o.betas)
+    for n in (50, 200, 1000, 7):
+        p.set_timesteps(n)
+        o.set_timesteps(n)
+        assert torch.equal(p.timesteps, o.timesteps)
+    p.set_timesteps(50)
+    c = p._coef(980)
+    a_t, a_p = o.alphas_cumprod[980], o.alphas_cumprod[960]
+    assert c[:4] == [float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5)]
+    assert p._coef(0)[2:4] == [1.0, 0.0] and c[5] == 0.0 and c[6] == 2.0
+    d = ps.DDPMScheduler(**SCHED)
+    assert d.clip_sample and d._coef(0)[4] == 0.0 and d._coef(10)[7] == 1.0
+    with pytest.raises(ValueError):
+        p.set_timesteps(2000)
+    with pytest.raises(NotImplementedError):
+        ps.DDIMScheduler(schedule="cosine")
+
+
+def test_state_dict_surface_and_loading():
+    import ccnet_amd.nets as pn
+    import oracle.nets as on
+    pu, ou = pn.DiffusionModelUNet(out_channels=4, **TINY), on.DiffusionModelUNet(out_channels=4, **TINY)
+    pc, oc = pn.ControlNet(**TINY, **TINY_CE), on.ControlNet(**TINY, **TINY_CE)
+    pv, ov = pn.AutoencoderKL(**TINY_VAE), on.AutoencoderKL(**TINY_VAE)
+    for p, o in ((pu, ou), (pc, oc), (pv, ov)):
+        ps_, os_ = p.state_dict(), o.state_dict()
+        assert list(ps_.keys()) == list(os_.keys())
+        assert all(ps_[k].shape == os_[k].shape for k in ps_)
+        p.load_state_dict(os_)
+    # upstream zero-initialises these
+    assert pu.out[2].conv.weight.abs().sum() == 0 and pc.controlnet_mid_block.weight.abs().sum() == 0
+    # wrapped zero-conv spelling `controlnet_down_blocks.k.conv.weight` is accepted too (Appendix A.8)
+    sd = {}
+    for k, v in oc.state_dict().items():
+        if k.startswith(("controlnet_down_blocks.", "controlnet_mid_block.")):
+            k = k.replace(".weight", ".conv.weight").replace(".bias", ".conv.bias")
+        sd[k] = v
+    pc.load_state_dict(sd)
+    # reference dispatch is by class-name substring (util.py:943, 1051)
+    assert "DiffusionModelUNet" in type(pu).__name__ and "ControlNetModel" not in type(pc).__name__
+    pn.adjust_class_embedding(pu)
+    on.adjust_class_embedding(ou)
+    assert pu.num_class_embeds == 99999 and list(pu.state_dict().keys()) == list(ou.state_dict().keys())
+    with pytest.raises(ValueError):
+        pn.adjust_class_embedding(torch.nn.Linear(1, 1))
+
+
+def test_product_has_no_cpu_fallback():
+    import ccnet_amd.nets as pn
+    import ccnet_amd.schedulers as ps
+    from ccnet_amd.lib import CcnetError
+    pu = pn.DiffusionModelUNet(out_channels=4, **TINY)
+    with pytest.raises(CcnetError):
+        pu(torch.zeros(1, 4, 16, 16), torch.tensor([1]), torch.zeros(1, 77, 64))
+    s = ps.DDIMScheduler(clip_sample=False, **SCHED)
+    s.set_timesteps(10)
+    with pytest.raises(CcnetError):
+        s.step(torch.zeros(1, 4, 8, 8), 900, torch.zeros(1, 4, 8, 8))
+    with pytest.raises(CcnetError):
+        pn.DiffusionModelUNet(spatial_dims=2, in_channels=4, out_channels=4, num_channels=[48, 96],
+                              attention_levels=[False, False], norm_num_groups=16)
+
+
+def test_reference_yaml_schema_loads():
+    """configs/controlnet/controlnet_v1.yaml schema (values restated in tests/golden/controlnet_v1.yaml) builds the
+    three product networks after the reference's own config mutation for the SD VAE (util.py:1221-1223)."""
+    import yaml
+    import ccnet_amd.nets as pn
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "controlnet_v1.yaml")))
+    cfg["controlnet"]["params"]["in_channels"] = 4
+    cfg["ldm"]["params"]["in_channels"] = 4
+    cfg["ldm"]["params"]["out_channels"] = 4
+    with torch.device("meta"):
+        c = pn.ControlNet(**cfg["controlnet"]["params"])
+        u = pn.DiffusionModelUNet(**cfg["ldm"]["params"])
+        v = pn.AutoencoderKL(**cfg["stage1"]["params"])
+    assert c.block_out_channels == [256, 512, 768] and u.out_channels == 4 and v.latent_channels == 3
+    import ccnet_amd.schedulers as ps
+    s = ps.DDPMScheduler(**cfg["ldm"]["scheduler"])
+    assert s.prediction_type == "v_prediction" and s.num_train_timesteps == 1000
+
+
+def test_synthetic_inputs_are_index_addressed():
+    from ccnet_amd.synthetic import make_batch
+    a = make_batch([3, 4, 5], seed=42, latent=(4, 16, 16), image=(64, 64), ctx_dim=64, acq=True)
+    b = make_batch([5], seed=42, latent=(4, 16, 16), image=(64, 64), ctx_dim=64, acq=True)
+    for k in ("noise", "cond", "prompt_embeds", "acquisition_time"):
+        assert torch.equal(a[k][2], b[k][0]), k
+    assert a["cond"].min() >= -1 and a["cond"].max() <= 1 and a["cond"].shape == (3, 1, 64, 64)
+    assert 60 <= a["acquisition_time"].min() and a["acquisition_time"].max() <= 1000
+    assert not torch.equal(a["noise"][0], a["noise"][1])
+
+
+# ------------------------------------------------------------------ C ABI
+def test_cabi_exports_every_declared_symbol():
+    from ccnet_amd import lib
+    hdr = open(os.path.join(ROOT, "include", "ccnet_hip.h")).read()
+    declared = set(re.findall(r"\b(ccnet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    l = lib.load()
+    for name in sorted(declared):
+        assert hasattr(l, name), f"{name} declared in include/ccnet_hip.h but not exported"
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    assert l.ccnet_arch().decode() == "gfx950" and l.ccnet_version() >= 1
+    assert l.ccnet_strerror(-1).decode().startswith("invalid")
+    import ctypes
+    assert ctypes.sizeof(lib.ConvParams) == 9 * 8 + 23 * 4 + 4 + 3 * 8 + 16  # struct layout of ccnet_conv_params
+
+
+# ------------------------------------------------------------------ sharding (world_size 2, gloo)
+def _worker(rank, world, port, n_total, bs, q):
+    import torch.distributed as dist
+    from ccnet_amd.distributed import sample_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccnet_amd.synthetic import make_noise
+
+    def run_batch(idx):  # stand-in for the GPU sampler: a deterministic function of the seed-indexed noise
+        n = make_noise(idx, 42, 4, 8, 8)
+        return {"latent": n * 2 + 1, "image_u8": (n[:, 0].abs() * 10).to(torch.uint8)}
+
+    out, mine = sample_sharded(run_batch, n_total, bs, world, rank, dist)
+    q.put((rank, list(mine), out["latent"].clone(), out["image_u8"].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,bs", [(10, 3), (7, 4)])
+def test_sharded_sampling_gloo_world2(n_total, bs):
+    import torch.multiprocessing as mp
+    from ccnet_amd.distributed import sample_sharded, shard_indices
+    from ccnet_amd.synthetic import make_noise
+    assert list(shard_indices(10, 4, 3)) == [9] and list(shard_indices(8, 8, 7)) == [7]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_total
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, bs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, _ = sample_sharded(lambda idx: {"latent": make_noise(idx, 42, 4, 8, 8) * 2 + 1,
+                                         "image_u8": (make_noise(idx, 42, 4, 8, 8)[:, 0].abs() * 10).to(torch.uint8)},
+                            n_total, bs, 1, 0)
+    covered = sorted(i for _, mine, _, _ in got for i in mine)
+    assert covered == list(range(n_total))
+    for _, _, lat, img in got:   # every rank holds the full, index-ordered result, identical to world_size 1
+        assert torch.equal(lat, ref["latent"]) and torch.equal(img, ref["image_u8"])

@@ -158,3 +158,50 @@ def test_g1_single_cfg_step(cuda):
     err = (res["latent"].cpu() - ref["latent"]).abs().max().item()
     print(f"G1 one-step latent max-abs {err:.3e}, rel_l2 {rel_l2(res['latent'], ref['latent']):.3e}")
     assert err <= 0.1
+
+
+def test_against_committed_golden(cuda):
+    """HIP path vs tests/golden/tiny_golden.npz (made by tests/golden/make_golden.py from the oracle): network
+    forwards, 8-step DDIM and DDPM sampling traces, decoded image and the uint8 mapping."""
+    import os
+    import numpy as np
+    import ccnet_amd.nets as pn
+    import ccnet_amd.schedulers as ps
+    from ccnet_amd.sampling import Sampler, to_uint8
+    from ccnet_amd.synthetic import init_weights
+    gold = {k: torch.from_numpy(v) for k, v in
+            np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_golden.npz")).items()}
+    cn, un, vae = pn.ControlNet(**TINY, **TINY_CE), pn.DiffusionModelUNet(out_channels=4, **TINY), \
+        pn.AutoencoderKL(**TINY_VAE)
+    pn.adjust_class_embedding(cn)
+    pn.adjust_class_embedding(un)
+    init_weights(cn, 11)
+    init_weights(un, 12)
+    init_weights(vae, 13)
+    cn, un, vae = cn.to(cuda).eval(), un.to(cuda).eval(), vae.to(cuda).eval()
+    g = {k: v.to(cuda) for k, v in gold.items() if k in ("x", "ctx", "empty", "cond", "acq")}
+    t = torch.tensor([500], device=cuda)
+    down, mid = cn(g["x"], t, g["cond"], 0.9, g["ctx"], g["acq"].reshape(-1, 1))
+    _check(down[0], gold["cn_down0"], "golden controlnet down[0]")
+    _check(down[-1], gold["cn_down_last"], "golden controlnet down[-1]")
+    _check(mid, gold["cn_mid"], "golden controlnet mid")
+    _check(un(g["x"], t, g["ctx"], g["acq"].reshape(-1, 1), down, mid), gold["unet_out"], "golden unet out")
+    _check(un(g["x"], t, g["ctx"], g["acq"].reshape(-1, 1)), gold["unet_plain"], "golden unet plain")
+    sch = ps.DDIMScheduler(clip_sample=False, **SCHED)
+    sch.set_timesteps(8)
+    assert sch.timesteps.tolist() == gold["ddim_ts"].tolist()
+    s = Sampler(cn, un, sch, vae, guidance_scale=3.0, conditioning_scale=1.0, scale_factor=0.5)
+    res = s.sample(g["x"], g["cond"], g["ctx"], g["empty"], g["acq"], record_latents=True)
+    errs = [(a.cpu() - b).abs().max().item() for a, b in zip(res["latents"], gold["ddim_latents"])]
+    print("golden ddim per-step latent max-abs:", " ".join(f"{e:.3e}" for e in errs))
+    assert max(errs) <= 0.1
+    assert psnr(res["image"], gold["ddim_image"]) >= 40.0
+    du8 = (to_uint8(res["image"]).cpu().int() - gold["ddim_u8"].int()).abs()
+    assert du8.float().mean().item() < 1.0 and du8.max().item() <= 12   # 8-bit image within ~1 grey level on average
+    dsch = ps.DDPMScheduler(**SCHED)
+    dsch.set_timesteps(8)
+    s2 = Sampler(cn, un, dsch, None, guidance_scale=3.0, conditioning_scale=1.0, scale_factor=0.5)
+    dres = s2.sample(g["x"], g["cond"], g["ctx"], g["empty"], g["acq"],
+                     ddpm_noise=[n.to(cuda) for n in gold["ddpm_noise"]], record_latents=True)
+    derr = [(a.cpu() - b).abs().max().item() for a, b in zip(dres["latents"], gold["ddpm_latents"])]
+    assert max(derr) <= 0.1, derr
