@@ -119,23 +119,34 @@ __global__ __launch_bounds__(AT_THREADS) void attn_d64_kernel(const AttnArgs a) 
         // scale into the log2 domain, mask keys beyond Skv (only possible in the last tile)
         const int kbase = t * KV_TILE + 4 * hh;
         const bool tail = (t + 1) * KV_TILE > a.Skv;
-        float mx = -INFINITY;
+        if (tail) {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kbase + kbk * 32 + (e & 3) + 8 * (e >> 2);
+                    if (key >= a.Skv) s[kbk][e] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;  // raw-score maximum of this lane's 32 keys, then of the whole row
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = s[kbk][e] * a.scale_log2e;
-                if (tail) {
-                    const int key = kbase + kbk * 32 + (e & 3) + 8 * (e >> 2);
-                    if (key >= a.Skv) v = -INFINITY;
-                }
-                s[kbk][e] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kbk][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;
+        // deferred rescale: keep the old running max while no row of the wave grew by more than 2^THR; P then
+        // stays <= 2^THR (exact in fp32, a bf16 float afterwards) and the O / l rescale pass is skipped.
+        constexpr float THR = 6.0f;
+        if (!__all(mx - m_run <= THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        }
         float rs = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
@@ -145,16 +156,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_d64_kernel(const AttnArgs a) 
                 float p[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    p[j] = __builtin_amdgcn_exp2f(s[kbk][8 * sI + j] - m_new);
+                    p[j] = __builtin_amdgcn_exp2f(fmaf(s[kbk][8 * sI + j], a.scale_log2e, -m_run));
                     rs += p[j];
                 }
                 pf[kbk][sI] = __builtin_bit_cast(bf16x8, pack8(p));
             }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        l_run += rs;
 
         // O^T[d][q] += V^T[d][key] * P^T[key][q]
 #pragma unroll

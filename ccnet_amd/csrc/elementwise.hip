@@ -103,8 +103,9 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int ldx
             const float s = wave_sum(acc[j]);
             if (lane == 0 && b0 + j < B) {
                 float v = s + (bias ? bias[n] : 0.f);
-                if (silu_out) v = silu_f(v);
+                if (silu_out == 1) v = silu_f(v);
                 if (add) v += add[(long long)(b0 + j) * ldadd + n];
+                if (silu_out == 2) v = silu_f(v);  // activation after the additive term
                 out[(long long)(b0 + j) * ldo + n] = v;
             }
         }

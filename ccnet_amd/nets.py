@@ -242,7 +242,8 @@ class _Trunk(nn.Module):
                 "q2": plin(b.attn2.to_q.weight),
                 "kv2": plin(torch.cat([b.attn2.to_k.weight, b.attn2.to_v.weight], 0)),
                 "o2": (plin(b.attn2.to_out[0].weight), f32(b.attn2.to_out[0].bias)),
-                "ff1": (plin(b.ff.linear1.weight), f32(b.ff.linear1.bias)),
+                "ff1": (plin(ops.geglu_interleave(b.ff.linear1.weight.detach())),
+                        f32(ops.geglu_interleave(b.ff.linear1.bias.detach()))),
                 "ff2": (plin(b.ff.linear2.weight), f32(b.ff.linear2.bias)),
             }
 
@@ -307,9 +308,11 @@ class _Trunk(nn.Module):
                 cl = class_labels.to(device=dev, dtype=torch.float32).reshape(B, 1).contiguous()
                 c1 = ops.linear_f32(cl, pk["ce0"][0], pk["ce0"][1], silu_out=True)
                 add = ops.linear_f32(c1, pk["ce2"][0], pk["ce2"][1])
-        emb = ops.linear_f32(h, pk["te2"][0], pk["te2"][1], add=add)
+        # emb = time_embed(t_emb) + class_emb is only ever consumed as silu(emb) (ResnetBlock.time_emb_proj input),
+        # so the SiLU is applied once here instead of once per output row of the projection below
+        semb = ops.linear_f32(h, pk["te2"][0], pk["te2"][1], add=add, silu_out=2)
         # every resnet's time_emb_proj(silu(emb)) in one launch; resnets take column slices
-        return ops.linear_f32(emb, pk["tproj_w"], pk["tproj_b"], silu_in=True)
+        return ops.linear_f32(semb, pk["tproj_w"], pk["tproj_b"])
 
     def _context(self, context, B):
         if context is None:
@@ -367,8 +370,7 @@ class _Trunk(nn.Module):
         o = ops.attention_d64(q, kv[:, :inner], kv[:, inner:], B, heads, T, S, scale)
         t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
         n3 = ops.layernorm(t, inner, *p["ln3"])
-        f = ops.linear(n3, p["ff1"][0], p["ff1"][1], 8 * inner, inner)
-        gl = ops.geglu(f, 4 * inner)
+        gl = ops.linear(n3, p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)  # linear1 + GEGLU in one kernel
         t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
         ta = Act(t, x.N, x.H, x.W, inner)
         return ops.conv(ta, p["pout"][0], p["pout"][1], C_, R=1, pad=0, res1=x, res2=res2)

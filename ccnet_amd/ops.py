@@ -67,9 +67,10 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
         Wo = (Wl + 2 * pad - R) // stride + 1
     else:
         Ho, Wo = out_hw
+    cout_out = Cout // 2 if act == 2 else Cout  # GEGLU epilogue halves the width
     if out is None:
-        out = new_act(x.N, Ho, Wo, Cout, x.t.device)
-    out2 = new_act(x.N, Ho, Wo, Cout, x.t.device) if res2 is not None else None
+        out = new_act(x.N, Ho, Wo, cout_out, x.t.device)
+    out2 = new_act(x.N, Ho, Wo, cout_out, x.t.device) if res2 is not None else None
     p = _l.ConvParams()
     p.x1 = x.t.data_ptr(); p.x2 = _ptr(x2.t) if x2 is not None else None
     p.w = w.data_ptr(); p.bias = _ptr(bias); p.rowvec = _ptr(rowvec)
@@ -109,12 +110,21 @@ def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, Cin: int,
-           res1: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
-    """Row-matrix convenience over conv(): x2d [rows, >=Cin] bf16 -> [rows, Cout]."""
+           res1: Optional[torch.Tensor] = None, scale: float = 1.0, act: int = 0) -> torch.Tensor:
+    """Row-matrix convenience over conv(): x2d [rows, >=Cin] bf16 -> [rows, Cout] (Cout/2 with act=2, GEGLU)."""
     rows = x2d.shape[0]
     xa = Act(x2d, 1, rows, 1, Cin)
     ra = Act(res1, 1, rows, 1, Cout) if res1 is not None else None
-    return conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale).t
+    return conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale, act=act).t
+
+
+def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
+    """Reorder the rows of MLPBlock.linear1 (weight [2H, C] or bias [2H]; value half first, gate half second) into
+    alternating 32-row blocks [a0..31, g0..31, a32..63, g32..63, ...] as the act=2 epilogue expects."""
+    H = w.shape[0] // 2
+    a, g = w[:H], w[H:]
+    sh = (H // 32, 32) + tuple(w.shape[1:])
+    return torch.stack([a.reshape(sh), g.reshape(sh)], dim=1).reshape(w.shape).contiguous()
 
 
 def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
@@ -180,7 +190,7 @@ def timestep_embedding(t: torch.Tensor, B: int, dim: int, freqs: torch.Tensor) -
 
 
 def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], silu_in: bool = False,
-               silu_out: bool = False, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+               silu_out: int = 0, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _l.load()
     _need_cuda(x, w)
     B, K = x.shape

@@ -64,7 +64,8 @@ typedef struct ccnet_conv_params {
     int32_t stride, pad;  /* pad_lo; the high side is implied by Hout/Wout                      */
     int32_t ups;          /* 1, or 2 = nearest-neighbour x2 upsample folded into the gather     */
     int32_t ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec;  /* row strides in elements  */
-    int32_t act;          /* 0 none, 1 SiLU                                                     */
+    int32_t act;          /* 0 none, 1 SiLU, 2 GEGLU: w/bias rows interleave 32-row blocks of the value and
+                             gate halves of MLPBlock.linear1; out has Cout/2 columns = a * gelu_erf(gate)      */
     float scale;
     int32_t batch;        /* >1: batched plain GEMM (R==1); z-th problem uses the strides below */
     int64_t sx1, sw, so;  /* element strides between batch problems for x1, w, out              */
@@ -123,7 +124,8 @@ int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, float sc
 /* ------------------------------------------------------------------ K11
  * fp32 embedding path. timestep_embedding: emb[b][0:half]=cos(t_b*freqs), [half:dim]=sin (cos first);
  * freqs = exp(-ln(10000)*arange(half)/half) is computed once on the host in fp32.
- * linear_f32: y[b][n] = act_out( sum_k act_in(x[b][k]) * w[n][k] + bias[n] ) + add[b][n]
+ * linear_f32: y[b][n] = act_out( sum_k act_in(x[b][k]) * w[n][k] + bias[n] ) + add[b][n]   (silu_out = 1), or
+ *             y = silu( ... + bias + add )                                                  (silu_out = 2)
  * (time_embed, CCnet class_embedding MLP util.py:1128-1132, all time_emb_proj(silu(emb)) rows at once).
  */
 int ccnet_timestep_embedding(const float* t /*[nt]*/, int nt, int B, int dim, const float* freqs /*[dim/2]*/,

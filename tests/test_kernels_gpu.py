@@ -278,3 +278,17 @@ def test_cfg_scheduler_step_and_converters(cuda):
     import numpy as np
     refu8 = np.rint(np.clip((img.cpu().numpy().astype(np.float64) + 1) / 2, 0, 1) * 255).astype(np.uint8)[:, 0]
     assert np.abs(u8.numpy().astype(int) - refu8.astype(int)).max() <= 1  # fp32 vs fp64 rint ties
+
+
+@pytest.mark.parametrize("rows,C", [(300, 320), (4096, 640), (64, 1280)])
+def test_linear1_geglu_fused(cuda, rows, C):
+    """MLPBlock.linear1 + GEGLU in one launch (act=2) == a * gelu(gate) of the plain linear."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(cuda)
+    w = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).to(torch.bfloat16)
+    b = 0.3 * torch.randn(8 * C, generator=g)
+    out = ops.linear(x, ops.geglu_interleave(w).to(cuda), ops.geglu_interleave(b).to(cuda), 8 * C, C, act=2)
+    assert tuple(out.shape) == (rows, 4 * C)
+    a, gate = F.linear(x.float(), w.float().to(cuda), b.to(cuda)).chunk(2, dim=-1)
+    _close(out.float(), a * F.gelu(gate), atol=2e-2, what="linear1+geglu")
