@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--shapes", type=str, default="", help="write the per-shape conv timing table to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +172,13 @@ def main():
     dt = time.perf_counter() - t0
     roof = None
     if prof:
+        if args.shapes and rank == 0:
+            rows = sorted(ops.prof_shapes(), key=lambda r: -r[6])
+            with open(args.shapes, "w") as fh:
+                fh.write("M Cout K R flags launches ms TFLOP/s\n")
+                for M, Co, K, R, fl, n, ms_ in rows:
+                    fh.write(f"{int(M)} {int(Co)} {int(K)} {int(R)} {int(fl)} {int(n)} {ms_:.3f} "
+                             f"{2.0 * M * Co * K * n / (ms_ * 1e9):.1f}\n")
         ms, flops, launches = ops.prof_collect()
         ops.prof_enable(False)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

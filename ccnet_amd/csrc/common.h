@@ -41,7 +41,21 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the IEEE division sequence
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at the fp32 rounding level of the exact form):
+// one v_rcp_f32, one v_exp_f32 and a degree-5 Horner chain, branch-free
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_fast(g * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

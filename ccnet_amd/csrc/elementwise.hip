@@ -112,6 +112,66 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int ldx
     }
 }
 
+// fp32 linear on the fp32-input matrix core (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain): one wave computes a
+// 32 (output features) x 32 (batch rows) tile, streaming its 32 weight rows once with 16 B per lane and four
+// loads in flight.  A operand = w (lane: feature n0 + (l & 31), k-slot l >> 5), B operand = x (lane: batch row
+// l & 31, same k-slot); element e of a lane's float4 feeds MFMA e of the step, so the k order inside an 8-wide
+// step is permuted identically for both operands.
+__global__ __launch_bounds__(64) void linear_f32_mfma_kernel(const float* x, int ldx, int B, int b0, int K,
+                                                              const float* w, const float* bias, int Nout,
+                                                              int silu_in, int silu_out, const float* add,
+                                                              int ldadd, float* out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = blockIdx.x * 32;  // one wave per workgroup: the tile count is what fills the chip
+    if (n0 >= Nout) return;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n = min(n0 + l31, Nout - 1);        // clamped rows are computed and discarded
+    const int b = min(b0 + l31, B - 1);
+    const float* wr = w + (long long)n * K + 4 * hh;
+    const float* xr = x + (long long)b * ldx + 4 * hh;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    int k = 0;
+    for (; k + 32 <= K; k += 32) {
+        f32x4 wv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { wv[u] = *(const f32x4*)(wr + k + 8 * u); xv[u] = *(const f32x4*)(xr + k + 8 * u); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xe = silu_in ? silu_f(xv[u][e]) : xv[u][e];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][e], xe, acc, 0, 0, 0);
+            }
+    }
+    for (; k < K; k += 8) {
+        const f32x4 wv = *(const f32x4*)(wr + k), xv = *(const f32x4*)(xr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xe = silu_in ? silu_f(xv[e]) : xv[e];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], xe, acc, 0, 0, 0);
+        }
+    }
+    // D[i = feature][j = batch row]: lane holds column j = l31, rows i = (reg & 3) + 8 * (reg >> 2) + 4 * hh
+    const int bo = b0 + l31;
+    if (bo >= B) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nn = n0 + 8 * q + 4 * hh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (nn + e < Nout) {
+                float v = acc[4 * q + e] + (bias ? bias[nn + e] : 0.f);
+                if (silu_out == 1) v = silu_f(v);
+                if (add) v += add[(long long)bo * ldadd + nn + e];
+                if (silu_out == 2) v = silu_f(v);
+                out[(long long)bo * ldo + nn + e] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ edge convolutions
 // conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16; thread = (pixel, 8 couts); blockIdx.y = chunk of <= 256 couts
 // whose weights sit in LDS k-major ([tap][cout]) so the 8 weights a lane needs per tap are two ds_read_b128 and
@@ -365,6 +425,15 @@ extern "C" int ccnet_linear_f32(const float* x, int ldx, int B, int K, const flo
                                 int silu_in, int silu_out, const float* add, int ldadd, float* out, int ldo,
                                 void* stream) {
     if (!x || !w || !out || B <= 0 || K <= 0 || Nout <= 0) return CCNET_EINVAL;
+    if (K >= 64 && (K % 8) == 0 && (ldx % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
+        const int tasks = (Nout + 31) / 32;
+        for (int b0 = 0; b0 < B; b0 += 32) {
+            hipLaunchKernelGGL(linear_f32_mfma_kernel, dim3(tasks), dim3(64), 0, (hipStream_t)stream, x, ldx,
+                               B, b0, K, w, bias, Nout, silu_in, silu_out, add, ldadd, out, ldo);
+            CCNET_LAUNCH_CHECK();
+        }
+        return CCNET_OK;
+    }
     hipLaunchKernelGGL(linear_f32_kernel, dim3((Nout + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, B, K, w,
                        bias, Nout, silu_in, silu_out, add, ldadd, out, ldo);
     CCNET_LAUNCH_CHECK();

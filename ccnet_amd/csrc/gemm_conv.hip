@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float av = acc[2 * p][j][4 * q + e] + ba[e], gv = acc[2 * p + 1][j][4 * q + e] + bg[e];
-                        v[e] = av * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f)));
+                        v[e] = av * gelu_erf_f(gv);
                     }
                     *(f32x4*)(ep + l31 * EPW + p * 32 + 8 * q + 4 * hh) = v;
                 }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 }
 
 // ---------------------------------------------------------------- profiling hooks
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int M, Cout, K, R, flags; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
@@ -358,6 +358,31 @@ extern "C" int ccnet_prof_collect(double* ms, double* flops, int64_t* launches) 
     return CCNET_OK;
 }
 
+extern "C" int ccnet_prof_shapes(double* table, int max_rows) {
+    // rows of 7 doubles {M, Cout, K, R, flags, launches, ms}; flags: bit0 stride 2, bit1 upsample, bit2 two sources,
+    // bit3 GEGLU, bit4 res1, bit5 out2, bit6 batched.  Call before ccnet_prof_collect (which resets the records).
+    int n = 0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        const ProfRec& r = g_prof[i];
+        if (hipEventSynchronize(r.e1) != hipSuccess) return CCNET_ELAUNCH;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return CCNET_ELAUNCH;
+        int j = 0;
+        for (; j < n; ++j) {
+            double* q = table + 7 * j;
+            if (q[0] == r.M && q[1] == r.Cout && q[2] == r.K && q[3] == r.R && q[4] == r.flags) break;
+        }
+        if (j == n) {
+            if (n == max_rows) continue;
+            double* q = table + 7 * n++;
+            q[0] = r.M; q[1] = r.Cout; q[2] = r.K; q[3] = r.R; q[4] = r.flags; q[5] = 0; q[6] = 0;
+        }
+        table[7 * j + 5] += 1;
+        table[7 * j + 6] += t;
+    }
+    return n;
+}
+
 extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     if (!p || !p->x1 || !p->w || !p->out) return CCNET_EINVAL;
     if (p->R != 1 && p->R != 3) return CCNET_EUNSUP;
@@ -410,6 +435,9 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
         }
         rec = &g_prof[g_prof_used++];
         rec->flops = 2.0 * a.M * (double)p->Cout * (double)(a.KT * 64) * batch;
+        rec->M = a.M; rec->Cout = p->Cout; rec->K = a.KT * 64; rec->R = p->R;
+        rec->flags = (p->stride == 2) | ((p->ups == 2) << 1) | ((p->C2 > 0) << 2) | ((p->act == 2) << 3) |
+                     ((p->res1 != nullptr) << 4) | ((p->out2 != nullptr) << 5) | ((batch > 1) << 6);
         (void)hipEventRecord(rec->e0, st);
     }
     const bool geglu = p->act == 2;

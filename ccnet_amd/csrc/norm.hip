@@ -43,9 +43,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
             float s[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-            for (int p = p0 + my_row; p < p1; p += rows_par) {
+            const long long rb = (long long)n * a.HW;
+            int p = p0 + my_row;
+            // four independent 16-B loads in flight per lane: this pass is pure HBM streaming
+            for (; p + 3 * rows_par < p1; p += 4 * rows_par) {
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = gn_load(a, rb + p + u * rows_par, col * 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    unpack8(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                }
+            }
+            for (; p < p1; p += rows_par) {
                 float f[8];
-                unpack8(gn_load(a, (long long)n * a.HW + p, col * 8), f);
+                unpack8(gn_load(a, rb + p, col * 8), f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
@@ -70,7 +85,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
-    __shared__ float s_a[GN_MAXC], s_b[GN_MAXC];
     __shared__ float s_mean[64], s_rstd[64];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     if (tid < a.groups) {
@@ -88,27 +102,41 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
         s_rstd[tid] = rsqrtf(m2 / cnt + a.eps);
     }
     __syncthreads();
-    for (int c = tid; c < a.C; c += GN_THREADS) {
-        const int g = c / a.cpg;
-        const float A = s_rstd[g] * a.gamma[c];
-        s_a[c] = A;
-        s_b[c] = a.beta[c] - s_mean[g] * A;
-    }
-    __syncthreads();
+    // a thread owns a fixed 8-channel column: its scale / shift live in registers, rows are streamed four at a time
     const int cols = a.C / 8;
     const int p0 = chunk * a.ppc, p1 = min(a.HW, p0 + a.ppc);
-    const int total = (p1 - p0) * cols;
-    for (int idx = tid; idx < total; idx += GN_THREADS) {
-        const int p = p0 + idx / cols, col = idx % cols;
-        const long long row = (long long)n * a.HW + p;
-        float f[8];
-        unpack8(gn_load(a, row, col * 8), f);
+    const int cstride = cols < GN_THREADS ? cols : GN_THREADS;
+    const int rows_par = GN_THREADS / cstride;
+    const int my_col = tid % cstride, my_row = tid / cstride;
+    if (my_row >= rows_par) return;
+    const long long rb = (long long)n * a.HW;
+    for (int col = my_col; col < cols; col += cstride) {
+        float A[8], Bv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float v = f[e] * s_a[col * 8 + e] + s_b[col * 8 + e];
-            f[e] = a.silu ? silu_f(v) : v;
+            const int c = col * 8 + e, g = c / a.cpg;
+            A[e] = s_rstd[g] * a.gamma[c];
+            Bv[e] = a.beta[c] - s_mean[g] * A[e];
         }
-        *(u32x4*)(a.out + row * a.ldo + col * 8) = pack8(f);
+        auto emit = [&](const u32x4& v, long long row) {
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = f[e] * A[e] + Bv[e];
+                f[e] = a.silu ? silu_f(t) : t;
+            }
+            *(u32x4*)(a.out + row * a.ldo + col * 8) = pack8(f);
+        };
+        int p = p0 + my_row;
+        for (; p + 3 * rows_par < p1; p += 4 * rows_par) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = gn_load(a, rb + p + u * rows_par, col * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(v[u], rb + p + u * rows_par);
+        }
+        for (; p < p1; p += rows_par) emit(gn_load(a, rb + p, col * 8), rb + p);
     }
 }
 
@@ -127,50 +155,71 @@ void gn_plan(int N, int HW, int C, int& chunks, int& ppc) {
 // ------------------------------------------------------------------ LayerNorm: one wave per row
 constexpr int LN_MAXCH = 4;  // 8-channel chunks per lane -> C <= 2048
 
+// NCH = 8-channel chunks per lane, RW = rows per wave: all RW*NCH 16-B loads of a wave are issued before the first
+// use, so a wave keeps RW*NCH KiB in flight (this pass is pure HBM streaming).
+template <int NCH, int RW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const __bf16* x, int ldx, int rows, int C, float eps,
                                                         const float* gamma, const float* beta, __bf16* out,
                                                         int ldo) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= rows) return;
     const int cols = C / 8;
-    float f[LN_MAXCH][8];
-    float s = 0.f;
+    u32x4 raw[RW][NCH];
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k) {
-        const int col = lane + k * 64;
-        if (col < cols) {
-            unpack8(*(const u32x4*)(x + (long long)row * ldx + col * 8), f[k]);
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += f[k][e];
+        for (int k = 0; k < NCH; ++k) {
+            const int col = lane + k * 64;
+            const int row = min(row0 + r, rows - 1);
+            raw[r][k] = col < cols ? *(const u32x4*)(x + (long long)row * ldx + col * 8) : u32x4{0u, 0u, 0u, 0u};
         }
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    const float invC = 1.0f / (float)C;
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k) {
-        const int col = lane + k * 64;
-        if (col < cols) {
+    for (int r = 0; r < RW; ++r) {
+        float f[NCH][8];
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; q += d * d; }
+        for (int k = 0; k < NCH; ++k) {
+            unpack8(raw[r][k], f[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[k][e];  // zero-filled beyond C
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXCH; ++k) {
-        const int col = lane + k * 64;
-        if (col < cols) {
-            float o[8];
-            const f32x4 g0 = *(const f32x4*)(gamma + col * 8), g1 = *(const f32x4*)(gamma + col * 8 + 4);
-            const f32x4 b0 = *(const f32x4*)(beta + col * 8), b1 = *(const f32x4*)(beta + col * 8 + 4);
+        for (int k = 0; k < NCH; ++k) {
+            if (lane + k * 64 < cols) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (f[k][e] - mean) * rstd * g0[e] + b0[e];
-                o[4 + e] = (f[k][4 + e] - mean) * rstd * g1[e] + b1[e];
+                for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; q += d * d; }
             }
-            *(u32x4*)(out + (long long)row * ldo + col * 8) = pack8(o);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        if (row0 + r < rows) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int col = lane + k * 64;
+                if (col < cols) {
+                    float o[8];
+                    const f32x4 g0 = *(const f32x4*)(gamma + col * 8), g1 = *(const f32x4*)(gamma + col * 8 + 4);
+                    const f32x4 b0 = *(const f32x4*)(beta + col * 8), b1 = *(const f32x4*)(beta + col * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (f[k][e] - mean) * rstd * g0[e] + b0[e];
+                        o[4 + e] = (f[k][4 + e] - mean) * rstd * g1[e] + b1[e];
+                    }
+                    *(u32x4*)(out + (long long)(row0 + r) * ldo + col * 8) = pack8(o);
+                }
+            }
         }
     }
+}
+
+template <int NCH, int RW>
+void launch_layernorm(const __bf16* x, int ldx, int rows, int C, float eps, const float* gamma, const float* beta,
+                      __bf16* out, int ldo, hipStream_t st) {
+    hipLaunchKernelGGL((layernorm_kernel<NCH, RW>), dim3((rows + 4 * RW - 1) / (4 * RW)), dim3(256), 0, st, x, ldx, rows,
+                       C, eps, gamma, beta, out, ldo);
 }
 
 }  // namespace
@@ -211,8 +260,14 @@ extern "C" int ccnet_layernorm_bf16(const void* x, int ldx, int rows, int C, flo
     if (!x || !out || !gamma || !beta) return CCNET_EINVAL;
     if (rows <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8)) return CCNET_EINVAL;
     if (C > LN_MAXCH * 64 * 8) return CCNET_EUNSUP;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x, ldx, rows, C, eps, gamma, beta, (__bf16*)out, ldo);
+    const int nch = (C / 8 + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* xp = (const __bf16*)x;
+    __bf16* op = (__bf16*)out;
+    if (nch == 1) launch_layernorm<1, 4>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
+    else if (nch == 2) launch_layernorm<2, 4>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
+    else if (nch == 3) launch_layernorm<3, 2>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
+    else launch_layernorm<4, 2>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

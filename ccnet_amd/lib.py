@@ -19,7 +19,7 @@ EXPORTS = [
     "ccnet_geglu_bf16", "ccnet_attention_d64_bf16", "ccnet_softmax_rows_bf16", "ccnet_timestep_embedding",
     "ccnet_linear_f32", "ccnet_cfg_scheduler_step", "ccnet_nchw_f32_to_nhwc_bf16", "ccnet_nhwc_bf16_to_nchw_f32",
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
-    "ccnet_set_option",
+    "ccnet_set_option", "ccnet_prof_shapes",
 ]
 
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.ccnet_set_option.argtypes = [i, i]
     lib.ccnet_prof_enable.argtypes = [i]
     lib.ccnet_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.ccnet_prof_shapes.argtypes = [C.POINTER(C.c_double), i]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

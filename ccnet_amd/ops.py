@@ -299,3 +299,12 @@ def prof_collect():
     ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
     _l.check(_l.load().ccnet_prof_collect(C.byref(ms), C.byref(fl), C.byref(n)), "prof_collect")
     return ms.value, fl.value, n.value
+
+
+def prof_shapes(max_rows: int = 512):
+    """Per-shape (M, Cout, K, R, flags, launches, ms) rows of the recorded conv launches (before prof_collect)."""
+    buf = (C.c_double * (7 * max_rows))()
+    n = _l.load().ccnet_prof_shapes(buf, max_rows)
+    if n < 0:
+        _l.check(n, "prof_shapes")
+    return [tuple(buf[7 * i + j] for j in range(7)) for i in range(n)]

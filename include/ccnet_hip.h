@@ -164,6 +164,9 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* str
 int ccnet_set_option(int key, int value); /* key 0: conv operand staging, 1 = LDS-DMA (default), 0 = registers */
 int ccnet_prof_enable(int on);
 int ccnet_prof_collect(double* ms, double* flops, int64_t* launches);
+/* per-shape table of the recorded launches: rows of 7 doubles {M, Cout, K, R, flags, launches, ms}; returns the row
+ * count (or a negative code). Call before ccnet_prof_collect, which resets the records. */
+int ccnet_prof_shapes(double* table /*host*/, int max_rows);
 
 #ifdef __cplusplus
 }

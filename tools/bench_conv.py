@@ -33,6 +33,10 @@ SHAPES = [
     ("U0 conv3x3 2560->1280 @8", 32, 8, 1280, 1280, 1280, 3, 1, 1),
     ("up conv3x3 1280->1280 8->16", 32, 8, 1280, 0, 1280, 3, 1, 2),
     ("down conv3x3 s2 320 64->32", 32, 64, 320, 0, 320, 3, 2, 1),
+    ("L0 o-proj 320->320 +res @64", 32, 64, 320, 0, 320, 1, 1, 1, True),
+    ("L1 o-proj 640->640 +res @32", 32, 32, 640, 0, 640, 1, 1, 1, True),
+    ("L2 o-proj 1280->1280 +res @16", 32, 16, 1280, 0, 1280, 1, 1, 1, True),
+    ("mid 1x1 1280->1280 @8", 32, 8, 1280, 0, 1280, 1, 1, 1),
     ("VAE conv3x3 128->128 @512 N=4", 4, 512, 128, 0, 128, 3, 1, 1),
     ("VAE conv3x3 256->256 @256 N=8", 8, 256, 256, 0, 256, 3, 1, 1),
 ]
@@ -52,7 +56,9 @@ def main():
         lib.load().ccnet_set_option(1, args.dbg_zero)
     dev = torch.device("cuda:0")
     tot_f, tot_t = 0.0, 0.0
-    for name, N, H, C1, C2, Cout, R, stride, ups in SHAPES:
+    for shape in SHAPES:
+        name, N, H, C1, C2, Cout, R, stride, ups = shape[:9]
+        with_res = len(shape) > 9 and shape[9]
         if args.filter and args.filter not in name:
             continue
         g = torch.Generator(device=dev).manual_seed(1)
@@ -61,31 +67,34 @@ def main():
         K = R * R * (C1 + C2)
         w = (torch.randn(Cout, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
         b = torch.randn(Cout, device=dev, generator=g)
-        res = []
+        Ho = H * ups // stride
+        res = Act(torch.randn(N * Ho * Ho, Cout, device=dev, generator=g).to(torch.bfloat16), N, Ho, Ho, Cout) \
+            if with_res else None
+        rs = []
         for cfg in cfgs:
             _lib.load().ccnet_set_option(0, cfg)
             try:
                 for _ in range(2):
-                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2)
+                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res)
             except Exception as e:  # report and keep sweeping
                 print(f"cfg {cfg} failed: {e}", flush=True)
-                res.append((0.0, 1e9))
+                rs.append((0.0, 1e9))
                 continue
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
-                o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2)
+                o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
             flops = 2.0 * o.rows * Cout * K
-            res.append((flops / ms / 1e9, ms))
-        best = max(range(len(cfgs)), key=lambda i: res[i][0])
+            rs.append((flops / ms / 1e9, ms))
+        best = max(range(len(cfgs)), key=lambda i: rs[i][0])
         tot_f += flops
-        tot_t += res[best][1]
-        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c}:{r[0]:6.0f}" for c, r in zip(cfgs, res))
-              + f"  best c{cfgs[best]} {res[best][1] * 1e3:7.1f} us", flush=True)
+        tot_t += rs[best][1]
+        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c}:{r[0]:6.0f}" for c, r in zip(cfgs, rs))
+              + f"  best c{cfgs[best]} {rs[best][1] * 1e3:7.1f} us", flush=True)
     if tot_t:
         print(f"{'TOTAL of best (equal weight)':34s} {tot_f / tot_t / 1e9:7.1f} TF/s")
 
