@@ -29,7 +29,7 @@ struct ConvArgs {
     int N, Hin, Win, Hout, Wout, C1, C2, Cout, R, stride, pad, ups;
     int ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec, act;
     float scale;
-    int M, HWout, KT, CT1, CT, tilesN, tiles;
+    int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
     long long sx1, sw, so;
     unsigned x1_bytes, x2_bytes, w_bytes;
 };
@@ -45,14 +45,19 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wa
 // GEGLU = true: the packed weight rows interleave 32-row blocks of the "a" half and the "gate" half of an
 // MLPBlock(act="GEGLU").linear1, so accumulators (2p, j) and (2p+1, j) of a wave hold a and gate of the same
 // outputs in the same lane/register; the epilogue writes a * gelu_erf(gate) (Cout/2 columns).
-template <int WM, int WN, int TJ, int TI, bool GEGLU>
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int NT = 64 * WM * WN, BM = 32 * TJ * WM, BN = 32 * TI * WN;
-    constexpr int RPP = NT / 8;            // tile rows covered by one pass of all threads (8 x 16 B per row)
+    static_assert(BK == 64 || BK == 32, "K-step of 64 or 32 channels");
+    constexpr int CPW = BK / 8;            // 16-B chunks per tile row
+    constexpr int RB = BK * 2;             // bytes per tile row
+    constexpr int RPP = NT / CPW;          // tile rows covered by one pass of all threads
     constexpr int NX = BM / RPP, NW = BN / RPP;
     constexpr int NL = NX + NW;            // DMA instructions per thread per K-step
-    constexpr int STAGE = (BM + BN) * 128;  // bytes per pipeline stage
-    constexpr int EPW = 32 * TI + 4;        // epilogue patch row stride in floats
+    constexpr int STAGE = (BM + BN) * RB;  // bytes per pipeline stage
+    constexpr int KS = BK / 16;            // MFMA k-steps per K-step
+    constexpr int EPG = 2;                  // 32-column output blocks per epilogue pass
+    constexpr int EPW = 32 * EPG + 4;       // epilogue patch row stride in floats
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows per DMA pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -68,7 +73,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const int m0 = (tile / a.tilesN) * BM, n0 = (tile % a.tilesN) * BN;
+    // tile order inside an XCD's contiguous range: N-fastest keeps the gathered pixel panel hot in that L2 (big-M
+    // layers); M-fastest (mfast) keeps a weight panel hot and lets each XCD stream only its share of the weights
+    // from HBM (small-M, deep-K layers whose weights exceed the activations).
+    const int m0 = (a.mfast ? tile % a.tilesM : tile / a.tilesN) * BM;
+    const int n0 = (a.mfast ? tile / a.tilesM : tile % a.tilesN) * BN;
     const int z = blockIdx.z;
 
     const __bf16* x1 = a.x1 + (long long)z * a.sx1;
@@ -77,7 +86,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, a.w_bytes, 0x00020000);
 
-    const int lrow = tid >> 3, lchunk = tid & 7;
+    const int lrow = tid / CPW, lchunk = tid % CPW;
+    // 16-B chunk swizzle (applied on the DMA source and on the fragment read): conflict-free ds_read_b128
+    auto swz_of = [](int r) { return BK == 64 ? (r >> 1) & 7 : (r >> 2) & 3; };
 
     // per-thread gather rows: image index and top-left input coordinate of each output pixel
     int xn[NX], xiy0[NX], xix0[NX];
@@ -92,12 +103,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         } else {
             xn[i] = -1; xiy0[i] = 0; xix0[i] = 0;
         }
-        xsw[i] = (unsigned)((lchunk ^ ((r >> 1) & 7)) << 3);
+        xsw[i] = (unsigned)((lchunk ^ swz_of(r)) << 3);
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int r = lrow + i * RPP, n = n0 + r;
-        woff[i] = n < a.Cout ? (unsigned)(n * a.ldw + ((lchunk ^ ((r >> 1) & 7)) << 3)) * 2u : OOB;
+        woff[i] = n < a.Cout ? (unsigned)(n * a.ldw + ((lchunk ^ swz_of(r)) << 3)) * 2u : OOB;
     }
     const int Hl = a.Hin * a.ups, Wl = a.Win * a.ups, ush = a.ups >> 1;
 
@@ -116,21 +127,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     int tap_n = 0, cc_n = 0, kt_n = 0;
     auto issue_slice = [&](int s, int lo, int hi) {
         char* xb = smem + s * STAGE + wave * 1024;
-        char* wb = xb + BM * 128;
+        char* wb = xb + BM * RB;
         const bool src2 = cc_n >= a.CT1;
-        const unsigned co = (unsigned)((src2 ? cc_n - a.CT1 : cc_n) * 64);
+        const unsigned co = (unsigned)((src2 ? cc_n - a.CT1 : cc_n) * BK);
         const unsigned ld = (unsigned)(src2 ? a.ldx2 : a.ldx1);
-        const unsigned kb = (unsigned)kt_n * 128u;
+        const unsigned kb = (unsigned)kt_n * (unsigned)RB;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             if (l < lo || l >= hi) continue;
             if (l < NX) {
                 const unsigned vo = pix[l] < 0 ? OOB : ((unsigned)pix[l] * ld + co + xsw[l]) * 2u;
-                if (!src2) buf_dma16(r1, xb + l * RPP * 128, vo);
-                else buf_dma16(r2, xb + l * RPP * 128, vo);
+                if (!src2) buf_dma16(r1, xb + l * RPP * RB, vo);
+                else buf_dma16(r2, xb + l * RPP * RB, vo);
             } else {
                 const int i = l - NX;
-                buf_dma16(rw, wb + i * RPP * 128, woff[i] == OOB ? OOB : woff[i] + kb);
+                buf_dma16(rw, wb + i * RPP * RB, woff[i] == OOB ? OOB : woff[i] + kb);
             }
         }
     };
@@ -147,120 +158,143 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int swz = (l31 >> 1) & 7;
-    const int xrow_off = (wm * 32 * TJ + l31) * 128, wrow_off = (wn * 32 * TI + l31) * 128;
+    const int swz = swz_of(l31);
+    const int xrow_off = (wm * 32 * TJ + l31) * RB, wrow_off = (wn * 32 * TI + l31) * RB;
 
+    // NS-stage ring, prefetch distance NS-1 K-steps: step kt's MFMAs run while the DMAs of steps kt+1 .. kt+NS-1 are in
+    // flight.  The wait that ends a step is COUNTED (all but the newest NS-2 steps' DMAs retired) and the barrier is
+    // a raw s_barrier, so loads stay in flight across it; the stage refilled during step kt is the one read during
+    // step kt-1, which every wave has left before it passed that step's barrier.
+    static_assert(NS >= 2 && NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
     set_tap(0);
-    issue_slice(0, 0, NL);
-    advance();
-    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) {
+        if (p < a.KT) {
+            if (p > 0 && cc_n == 0) set_tap(tap_n);
+            issue_slice(p, 0, NL);
+            advance();
+        }
+    }
+    if (a.KT >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int s = 0, sn = NS - 1;  // stage being read, stage being refilled
     for (int kt = 0; kt < a.KT; ++kt) {
-        const bool more = kt + 1 < a.KT;
-        const int s = kt & 1;
+        const bool more = kt + NS - 1 < a.KT;
         const char* xb = smem + s * STAGE;
-        const char* wb = xb + BM * 128;
+        const char* wb = xb + BM * RB;
         if (more && cc_n == 0) set_tap(tap_n);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int co = ((2 * ks + hh) ^ swz) << 4;
             bf16x8 af[TI], bfr[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * 128 + co);
+            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * RB + co);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * 128 + co);
-            if (more) issue_slice(s ^ 1, (NL * ks) / 4, (NL * (ks + 1)) / 4);
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * RB + co);
+            if (more) issue_slice(sn, (NL * ks) / KS, (NL * (ks + 1)) / KS);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (more) advance();
-        __syncthreads();  // carries the s_waitcnt vmcnt(0) that retires the DMA of the next stage
+        if (more) {
+            advance();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (NS - 2)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        s = s + 1 == NS ? 0 : s + 1;
+        sn = sn + 1 == NS ? 0 : sn + 1;
     }
 
     // ---------------------------------------------------------------- epilogue
     static_assert(!GEGLU || (TI % 2) == 0, "GEGLU pairs accumulator blocks");
     constexpr int TIO = GEGLU ? TI / 2 : TI;  // 32-column output blocks per wave
-    constexpr int CPR = 4 * TIO;              // 8-float chunks per patch row
     float* ep = (float*)smem + wave * (32 * EPW);
     __bf16* outp = a.out + (long long)z * a.so;
     const int cout_out = GEGLU ? a.Cout / 2 : a.Cout;
     const int ncol0 = GEGLU ? n0 / 2 + wn * 16 * TI : n0 + wn * 32 * TI;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        if constexpr (GEGLU) {
 #pragma unroll
-            for (int p = 0; p < TI / 2; ++p)
+        for (int ob0 = 0; ob0 < TIO; ob0 += EPG) {  // EPG output blocks (<= 64 columns) through the patch per pass
+            const int cnt = TIO - ob0 < EPG ? TIO - ob0 : EPG;
+#pragma unroll
+            for (int oo = 0; oo < EPG; ++oo) {
+                const int ob = ob0 + oo;
+                if (ob >= TIO) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int nb = n0 + wn * 32 * TI + 2 * p * 32 + 8 * q + 4 * hh;  // packed row of the "a" part
-                    f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias && nb + 32 < a.Cout) { ba = *(const f32x4*)(a.bias + nb); bg = *(const f32x4*)(a.bias + nb + 32); }
                     f32x4 v;
+                    if constexpr (GEGLU) {
+                        const int nb = n0 + wn * 32 * TI + 2 * ob * 32 + 8 * q + 4 * hh;  // packed row of the "a" part
+                        f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+                        if (a.bias && nb + 32 < a.Cout) { ba = *(const f32x4*)(a.bias + nb); bg = *(const f32x4*)(a.bias + nb + 32); }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float av = acc[2 * p][j][4 * q + e] + ba[e], gv = acc[2 * p + 1][j][4 * q + e] + bg[e];
-                        v[e] = av * gelu_erf_f(gv);
+                        for (int e = 0; e < 4; ++e) {
+                            const float av = acc[2 * ob][j][4 * q + e] + ba[e], gv = acc[2 * ob + 1][j][4 * q + e] + bg[e];
+                            v[e] = av * gelu_erf_f(gv);
+                        }
+                    } else {
+                        v = f32x4{acc[ob][j][4 * q], acc[ob][j][4 * q + 1], acc[ob][j][4 * q + 2], acc[ob][j][4 * q + 3]};
                     }
-                    *(f32x4*)(ep + l31 * EPW + p * 32 + 8 * q + 4 * hh) = v;
-                }
-        } else {
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *(f32x4*)(ep + l31 * EPW + i * 32 + 8 * q + 4 * hh) = v;
-                }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 2 * TIO; ++it) {
-            const int idx = lane + 64 * it;
-            const int row = idx / CPR, lc = idx - row * CPR;
-            const int m = m0 + wm * 32 * TJ + j * 32 + row;
-            const int ncol = ncol0 + lc * 8;
-            const f32x4 v0 = *(const f32x4*)(ep + row * EPW + lc * 8);
-            const f32x4 v1 = *(const f32x4*)(ep + row * EPW + lc * 8 + 4);
-            if (m < a.M && ncol < cout_out) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                if (!GEGLU && a.bias) {
-                    const f32x4 b0 = *(const f32x4*)(a.bias + ncol), b1 = *(const f32x4*)(a.bias + ncol + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (a.rowvec) {
-                    const float* rv = a.rowvec + (long long)(m / a.HWout) * a.ld_rowvec + ncol;
-                    const f32x4 t0 = *(const f32x4*)rv, t1 = *(const f32x4*)(rv + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
-                }
-                if (a.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= a.scale;
-                if (a.res1) {
-                    float r[8];
-                    unpack8(*(const u32x4*)(a.res1 + (long long)m * a.ldres1 + ncol), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
-                *(u32x4*)(outp + (long long)m * a.ldo + ncol) = pack8(v);
-                if (a.out2) {
-                    float r[8];
-                    unpack8(*(const u32x4*)(a.res2 + (long long)m * a.ldres2 + ncol), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                    *(u32x4*)(a.out2 + (long long)m * a.ldo2 + ncol) = pack8(v);
+                    *(f32x4*)(ep + l31 * EPW + oo * 32 + 8 * q + 4 * hh) = v;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            const int cpr = 4 * cnt;  // 8-float chunks per patch row in this pass
+#pragma unroll
+            for (int it = 0; it < 2 * EPG; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx / cpr, lc = idx - row * cpr;
+                const int m = m0 + wm * 32 * TJ + j * 32 + row;
+                const int ncol = ncol0 + ob0 * 32 + lc * 8;
+                if (row < 32 && m < a.M && ncol < cout_out) {
+                    const f32x4 v0 = *(const f32x4*)(ep + row * EPW + lc * 8);
+                    const f32x4 v1 = *(const f32x4*)(ep + row * EPW + lc * 8 + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                    if (!GEGLU && a.bias) {
+                        const f32x4 b0 = *(const f32x4*)(a.bias + ncol), b1 = *(const f32x4*)(a.bias + ncol + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    }
+                    if (a.rowvec) {
+                        const float* rv = a.rowvec + (long long)(m / a.HWout) * a.ld_rowvec + ncol;
+                        const f32x4 t0 = *(const f32x4*)rv, t1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+                    }
+                    if (a.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= a.scale;
+                    if (a.res1) {
+                        float r[8];
+                        unpack8(*(const u32x4*)(a.res1 + (long long)m * a.ldres1 + ncol), r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+                    *(u32x4*)(outp + (long long)m * a.ldo + ncol) = pack8(v);
+                    if (a.out2) {
+                        float r[8];
+                        unpack8(*(const u32x4*)(a.res2 + (long long)m * a.ldres2 + ncol), r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                        *(u32x4*)(a.out2 + (long long)m * a.ldo2 + ncol) = pack8(v);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -271,24 +305,27 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 
 int g_force_cfg = -1;  // tuning: force a tile configuration (index into the dispatch below)
+int g_order = -1;     // tuning: force the tile order (0 N-fastest, 1 M-fastest, -1 = heuristic)
 int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, bit1 = w descriptor empty
 
-template <int WM, int WN, int TJ, int TI, bool GEGLU>
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
-    constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EP = (NT / 64) * 32 * (32 * TI + 4) * 4;
+    constexpr int LDS_MAIN = NS * (BM + BN) * BK * 2, LDS_EP = (NT / 64) * 32 * (32 * 2 + 4) * 4;
     constexpr int LDS = LDS_MAIN > LDS_EP ? LDS_MAIN : LDS_EP;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU>,
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set = true;
     }
     ConvArgs b = a;
+    b.CT1 = a.C1 / BK; b.CT = (a.C1 + a.C2) / BK; b.KT = a.R * a.R * b.CT;
     b.tilesN = (a.Cout + BN - 1) / BN;
-    b.tiles = ((a.M + BM - 1) / BM) * b.tilesN;
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU>), dim3(b.tiles, 1, batch), dim3(NT), LDS, st, b);
+    b.tilesM = (a.M + BM - 1) / BM;
+    b.tiles = b.tilesM * b.tilesN;
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK>), dim3(b.tiles, 1, batch), dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }
@@ -309,6 +346,19 @@ const TileCfg kCfgs[] = {
     {256, 256, launch<4, 2, 2, 4, false>, nullptr},                     // 10: 8 waves
     {256, 128, launch<4, 2, 2, 2, false>, nullptr},                     // 11: 8 waves
     {128, 160, launch<2, 1, 2, 5, false>, nullptr},                     // 12: 2 waves
+    {128, 128, launch<2, 2, 2, 2, false, 3>, launch<2, 2, 2, 2, true, 3>},   // 13: 3 stages
+    {128, 128, launch<2, 2, 2, 2, false, 4>, nullptr},                  // 14: 4 stages
+    {256, 128, launch<4, 2, 2, 2, false, 3>, nullptr},                  // 15: 8 waves, 3 stages
+    {128, 64, launch<2, 1, 2, 2, false, 3>, nullptr},                   // 16: 2 waves, 3 stages
+    {128, 256, launch<2, 2, 2, 4, false, 3>, nullptr},                  // 17: 3 stages
+    {256, 256, launch<4, 2, 2, 4, false, 2>, nullptr},                  // 18: = 10
+    {128, 128, launch<4, 2, 1, 2, false, 3>, nullptr},                  // 19: 8 waves (32 x 64 per wave), 3 stages
+    {256, 256, launch<4, 2, 2, 4, false, 4, 32>, launch<4, 2, 2, 4, true, 4, 32>},  // 20: 8 waves, 4 x 32-deep stages
+    {256, 128, launch<4, 2, 2, 2, false, 4, 32>, launch<4, 2, 2, 2, true, 4, 32>},  // 21
+    {128, 128, launch<2, 2, 2, 2, false, 4, 32>, launch<2, 2, 2, 2, true, 4, 32>},  // 22: 64 KB, two blocks per CU
+    {256, 320, launch<4, 2, 2, 5, false, 2>, nullptr},                  // 23: 8 waves
+    {128, 256, launch<2, 4, 2, 2, false, 3>, nullptr},                  // 24: 8 waves, 3 stages
+    {256, 128, launch<4, 2, 2, 2, false, 6, 32>, nullptr},              // 25: 6 x 32-deep (144 KB)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -317,9 +367,19 @@ int pick_cfg(int M, int Cout, int K, int batch, bool geglu) {
     auto blocks = [&](int c) {
         return (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((Cout + kCfgs[c].bn - 1) / kCfgs[c].bn) * batch;
     };
-    // measured on MI355X at CFG batch 32 (tools/bench_conv.py): the 128x320 tile (64 px x 160 cout per wave) wins
-    // wherever Cout is a multiple of 320 and K is deep enough to amortise its epilogue; 256x256 wins on very wide
-    // layers (GEGLU linear1) and the 256-channel VAE level; 128x128 elsewhere.
+    // Measured on MI355X at CFG batch 32 with HBM-cold weights (tools/bench_conv.py --cold).  The L2 -> LDS path
+    // delivers ~64 B/clk/CU, so a tile's DMA time per K-step, (BM+BN)*128 B / 64, must stay well under its MFMA time
+    // BM*BN/32 clk: the 8-wave 256x320 / 256x256 tiles (45-50 % DMA duty) beat 128x128 (100 %) wherever the layer
+    // still yields >= ~200 tiles; smaller-M layers trade tile size for tile count.
+    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * batch; };
+    if (geglu) {
+        if ((Cout % 256) == 0 && tiles(256, 256) >= 200) return 20;
+    } else {
+        if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
+        if ((Cout % 256) == 0 && tiles(256, 256) >= 150) return Cout == 256 ? 10 : 20;
+        if ((Cout % 128) == 0 && tiles(256, 128) >= 200) return 15;
+        if (M <= 4096 && tiles(128, 128) >= 100) return 19;
+    }
     const bool n128 = (Cout % 128) == 0 || Cout >= 512;
     if (!geglu && (Cout % 320) == 0 && K >= 1280 && blocks(3) >= 128) return 3;
     if ((Cout % 256) == 0 && (Cout >= 4096 || Cout == 256) && blocks(6) >= 256) return 6;
@@ -333,6 +393,7 @@ int pick_cfg(int M, int Cout, int K, int batch, bool geglu) {
 extern "C" int ccnet_set_option(int key, int value) {
     if (key == 0) { g_force_cfg = value; return CCNET_OK; }  // force conv tile configuration (-1 = heuristic)
     if (key == 1) { g_dbg_zero = value; return CCNET_OK; }
+    if (key == 2) { g_order = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
@@ -417,6 +478,10 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     a.M = p->N * p->Hout * p->Wout; a.HWout = p->Hout * p->Wout;
     a.CT1 = p->C1 / 64; a.CT = (p->C1 + p->C2) / 64; a.KT = p->R * p->R * a.CT;
     a.sx1 = p->sx1; a.sw = p->sw; a.so = p->so;
+    {
+        const long long wbytes = (long long)p->Cout * a.KT * 128, xbytes = (long long)p->N * p->Hin * p->Win * a.CT * 128;
+        a.mfast = g_order >= 0 ? g_order : (wbytes > xbytes);
+    }
     const long long xb1 = ((long long)p->N * p->Hin * p->Win - 1) * p->ldx1 * 2 + (long long)p->C1 * 2;
     const long long xb2 = p->C2 ? ((long long)p->N * p->Hin * p->Win - 1) * p->ldx2 * 2 + (long long)p->C2 * 2 : 0;
     const long long wb = ((long long)p->Cout - 1) * p->ldw * 2 + (long long)a.KT * 128;

@@ -48,12 +48,15 @@ def main():
     ap.add_argument("--filter", type=str, default="")
     ap.add_argument("--cfgs", type=str, default="-1", help="comma list of forced tile configs (-1 = heuristic)")
     ap.add_argument("--dbg-zero", type=int, default=0)
+    ap.add_argument("--order", type=int, default=-1, help="force tile order: 0 N-fastest, 1 M-fastest")
+    ap.add_argument("--cold", action="store_true", help="rotate over 12 weight copies so weights come from HBM")
     args = ap.parse_args()
     from ccnet_amd import lib as _lib
     cfgs = [int(c) for c in args.cfgs.split(",")]
     if args.dbg_zero:
         from ccnet_amd import lib
         lib.load().ccnet_set_option(1, args.dbg_zero)
+    _lib.load().ccnet_set_option(2, args.order)
     dev = torch.device("cuda:0")
     tot_f, tot_t = 0.0, 0.0
     for shape in SHAPES:
@@ -66,11 +69,15 @@ def main():
         x2 = Act(torch.randn(N * H * H, C2, device=dev, generator=g).to(torch.bfloat16), N, H, H, C2) if C2 else None
         K = R * R * (C1 + C2)
         w = (torch.randn(Cout, K, device=dev, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        ncopy = min(24, max(1, -(-320 * 2 ** 20 // (w.numel() * 2)))) if args.cold else 1
+        ws = [w] + [w.clone() for _ in range(ncopy - 1)]
         b = torch.randn(Cout, device=dev, generator=g)
         Ho = H * ups // stride
         res = Act(torch.randn(N * Ho * Ho, Cout, device=dev, generator=g).to(torch.bfloat16), N, Ho, Ho, Cout) \
             if with_res else None
         rs = []
+        _lib.load().ccnet_set_option(0, -1)
+        ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res).t.clone()
         for cfg in cfgs:
             _lib.load().ccnet_set_option(0, cfg)
             try:
@@ -81,10 +88,14 @@ def main():
                 rs.append((0.0, 1e9))
                 continue
             torch.cuda.synchronize()
+            o_chk = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res).t
+            if not torch.equal(o_chk, ref_out):
+                print(f"  !! cfg {cfg} differs from the heuristic config: max abs "
+                      f"{(o_chk.float() - ref_out.float()).abs().max().item():.3e}", flush=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(args.iters):
-                o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res)
+            for it in range(args.iters):
+                o = ops.conv(x1, ws[it % ncopy], b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
