@@ -359,6 +359,10 @@ const TileCfg kCfgs[] = {
     {256, 320, launch<4, 2, 2, 5, false, 2>, nullptr},                  // 23: 8 waves
     {128, 256, launch<2, 4, 2, 2, false, 3>, nullptr},                  // 24: 8 waves, 3 stages
     {256, 128, launch<4, 2, 2, 2, false, 6, 32>, nullptr},              // 25: 6 x 32-deep (144 KB)
+    {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>},  // 26: 4 waves, 72 KB: two blocks per CU
+    {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr},              // 27: 4 waves, 57 KB: two blocks per CU
+    {128, 128, launch<2, 2, 2, 2, false, 3, 32>, launch<2, 2, 2, 2, true, 3, 32>},  // 28: 48 KB: three blocks per CU
+    {256, 256, launch<4, 2, 2, 4, false, 2, 32>, launch<4, 2, 2, 4, true, 2, 32>},  // 29: 8 waves, 64 KB: two blocks per CU if registers allow
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
