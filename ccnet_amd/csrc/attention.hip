@@ -13,6 +13,7 @@
 // from ds_read_b64_tr_b16 on the row-major V tile.  O^T keeps the query on the lane as well, so the
 // running rescale is one scalar per lane.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -31,7 +32,9 @@ __device__ __forceinline__ s16x4 ds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_d64_kernel(const AttnArgs a) {
+// launch bound of 2 waves per SIMD: caps the kernel at 256 registers so hipcc keeps MFMA results in VGPRs (with 512
+// allowed it parks S and O in AGPRs and pays ~160 v_accvgpr moves per tile around the softmax).
+__global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 V0 K1 V1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_d64_kernel(const AttnArgs a) 
     issue_loads(0);
     store_stage(0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile_body = [&](int t, auto tail_c) {
+        constexpr bool tail = decltype(tail_c)::value;
         const bool more = t + 1 < ntiles;
         if (more) issue_loads(t + 1);
         const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
@@ -118,8 +122,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_d64_kernel(const AttnArgs a) 
         }
         // scale into the log2 domain, mask keys beyond Skv (only possible in the last tile)
         const int kbase = t * KV_TILE + 4 * hh;
-        const bool tail = (t + 1) * KV_TILE > a.Skv;
-        if (tail) {
+        if constexpr (tail) {
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
@@ -183,7 +186,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_d64_kernel(const AttnArgs a) 
                 }
         if (more) store_stage((t + 1) & 1);
         __syncthreads();
-    }
+    };
+    // only the last tile can hold keys beyond Skv: the masking code exists in that instance alone
+    const bool ragged = (a.Skv % KV_TILE) != 0;
+    for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::false_type{});
+    if (ragged) tile_body(ntiles - 1, std::true_type{});
+    else tile_body(ntiles - 1, std::false_type{});
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;

@@ -25,8 +25,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(unsigned short, h);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two floats -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN safe)
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
 }
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll
