@@ -247,29 +247,62 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            const int cpr = 4 * cnt;  // 8-float chunks per patch row in this pass
+            // A lane owns one 8-column chunk (lc) of rows r0, r0 + rstep, ...: the column-indexed operands (bias) are
+            // loaded once, and every row-indexed load of the pass (residuals, time-embedding rows) is ISSUED before
+            // the first use, so a wave pays one memory round trip per pass instead of one per item.
+            const int cpr = 4 * cnt;  // 8-float chunks per patch row in this pass (8 or 4)
+            const int rstep = 64 / cpr, nit = 32 / rstep;
+            const int lc = lane % cpr, r0 = lane / cpr;
+            const int ncol = ncol0 + ob0 * 32 + lc * 8;
+            const bool colok = ncol < cout_out;
+            const int mbase = m0 + wm * 32 * TJ + j * 32 + r0;
+            f32x4 bb0 = {0.f, 0.f, 0.f, 0.f}, bb1 = {0.f, 0.f, 0.f, 0.f};
+            if (!GEGLU && a.bias && colok) { bb0 = *(const f32x4*)(a.bias + ncol); bb1 = *(const f32x4*)(a.bias + ncol + 4); }
+            constexpr int MAXIT = 2 * EPG;
+            u32x4 rr1[MAXIT], rr2[MAXIT];
+            f32x4 tv0[MAXIT], tv1[MAXIT];
+            if (a.res1) {
 #pragma unroll
-            for (int it = 0; it < 2 * EPG; ++it) {
-                const int idx = lane + 64 * it;
-                const int row = idx / cpr, lc = idx - row * cpr;
-                const int m = m0 + wm * 32 * TJ + j * 32 + row;
-                const int ncol = ncol0 + ob0 * 32 + lc * 8;
-                if (row < 32 && m < a.M && ncol < cout_out) {
+                for (int it = 0; it < MAXIT; ++it) {
+                    const int m = mbase + it * rstep;
+                    if (it < nit && colok && m < a.M) rr1[it] = *(const u32x4*)(a.res1 + (long long)m * a.ldres1 + ncol);
+                }
+            }
+            if (a.out2) {
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it) {
+                    const int m = mbase + it * rstep;
+                    if (it < nit && colok && m < a.M) rr2[it] = *(const u32x4*)(a.res2 + (long long)m * a.ldres2 + ncol);
+                }
+            }
+            if (a.rowvec) {
+                // image of a row: wave-uniform when every 32-row block lies inside one image (HWout % 32 == 0)
+                const bool uni = (a.HWout & 31) == 0;
+                const int img_u = uni ? (m0 + wm * 32 * TJ + j * 32) / a.HWout : 0;
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it) {
+                    const int m = mbase + it * rstep;
+                    if (it < nit && colok && m < a.M) {
+                        const int img = uni ? img_u : m / a.HWout;
+                        const float* rv = a.rowvec + (long long)img * a.ld_rowvec + ncol;
+                        tv0[it] = *(const f32x4*)rv;
+                        tv1[it] = *(const f32x4*)(rv + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int row = r0 + it * rstep;
+                const int m = mbase + it * rstep;
+                if (it < nit && colok && m < a.M) {
                     const f32x4 v0 = *(const f32x4*)(ep + row * EPW + lc * 8);
                     const f32x4 v1 = *(const f32x4*)(ep + row * EPW + lc * 8 + 4);
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-                    if (!GEGLU && a.bias) {
-                        const f32x4 b0 = *(const f32x4*)(a.bias + ncol), b1 = *(const f32x4*)(a.bias + ncol + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                    }
+                    for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bb0[e]; v[4 + e] = v1[e] + bb1[e]; }
                     if (a.rowvec) {
-                        const float* rv = a.rowvec + (long long)(m / a.HWout) * a.ld_rowvec + ncol;
-                        const f32x4 t0 = *(const f32x4*)rv, t1 = *(const f32x4*)(rv + 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+                        for (int e = 0; e < 4; ++e) { v[e] += tv0[it][e]; v[4 + e] += tv1[it][e]; }
                     }
                     if (a.act == 1) {
 #pragma unroll
@@ -279,14 +312,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                     for (int e = 0; e < 8; ++e) v[e] *= a.scale;
                     if (a.res1) {
                         float r[8];
-                        unpack8(*(const u32x4*)(a.res1 + (long long)m * a.ldres1 + ncol), r);
+                        unpack8(rr1[it], r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                     }
                     *(u32x4*)(outp + (long long)m * a.ldo + ncol) = pack8(v);
                     if (a.out2) {
                         float r[8];
-                        unpack8(*(const u32x4*)(a.res2 + (long long)m * a.ldres2 + ncol), r);
+                        unpack8(rr2[it], r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += r[e];
                         *(u32x4*)(a.out2 + (long long)m * a.ldo2 + ncol) = pack8(v);

@@ -11,7 +11,8 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libccnet_hip.so"
+# CCNET_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants); default is the in-tree library
+LIB_PATH = Path(os.environ.get("CCNET_HIP_LIB", str(_HERE / "libccnet_hip.so")))
 
 EXPORTS = [
     "ccnet_strerror", "ccnet_version", "ccnet_arch", "ccnet_conv_gemm_bf16", "ccnet_conv_in_small",

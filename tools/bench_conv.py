@@ -37,6 +37,9 @@ SHAPES = [
     ("L1 o-proj 640->640 +res @32", 32, 32, 640, 0, 640, 1, 1, 1, True),
     ("L2 o-proj 1280->1280 +res @16", 32, 16, 1280, 0, 1280, 1, 1, 1, True),
     ("mid 1x1 1280->1280 @8", 32, 8, 1280, 0, 1280, 1, 1, 1),
+    ("L0 ff1+GEGLU 320->2560 @64", 32, 64, 320, 0, 2560, 1, 1, 1, False, 2),
+    ("L1 ff1+GEGLU 640->5120 @32", 32, 32, 640, 0, 5120, 1, 1, 1, False, 2),
+    ("L2 ff1+GEGLU 1280->10240 @16", 32, 16, 1280, 0, 10240, 1, 1, 1, False, 2),
     ("VAE conv3x3 128->128 @512 N=4", 4, 512, 128, 0, 128, 3, 1, 1),
     ("VAE conv3x3 256->256 @256 N=8", 8, 256, 256, 0, 256, 3, 1, 1),
 ]
@@ -62,6 +65,7 @@ def main():
     for shape in SHAPES:
         name, N, H, C1, C2, Cout, R, stride, ups = shape[:9]
         with_res = len(shape) > 9 and shape[9]
+        act = shape[10] if len(shape) > 10 else 0
         if args.filter and args.filter not in name:
             continue
         g = torch.Generator(device=dev).manual_seed(1)
@@ -77,25 +81,25 @@ def main():
             if with_res else None
         rs = []
         _lib.load().ccnet_set_option(0, -1)
-        ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res).t.clone()
+        ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act).t.clone()
         for cfg in cfgs:
             _lib.load().ccnet_set_option(0, cfg)
             try:
                 for _ in range(2):
-                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res)
+                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act)
             except Exception as e:  # report and keep sweeping
                 print(f"cfg {cfg} failed: {e}", flush=True)
                 rs.append((0.0, 1e9))
                 continue
             torch.cuda.synchronize()
-            o_chk = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res).t
+            o_chk = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act).t
             if not torch.equal(o_chk, ref_out):
                 print(f"  !! cfg {cfg} differs from the heuristic config: max abs "
                       f"{(o_chk.float() - ref_out.float()).abs().max().item():.3e}", flush=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for it in range(args.iters):
-                o = ops.conv(x1, ws[it % ncopy], b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res)
+                o = ops.conv(x1, ws[it % ncopy], b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
