@@ -291,8 +291,18 @@ def axpy_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_prof_on = False
+
+
 def prof_enable(on: bool) -> None:
+    """Bracket every conv launch with HIP events (bench.py roofline pass); incompatible with graph capture."""
+    global _prof_on
+    _prof_on = bool(on)
     _l.load().ccnet_prof_enable(int(on))
+
+
+def prof_is_enabled() -> bool:
+    return _prof_on
 
 
 def prof_collect():

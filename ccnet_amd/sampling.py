@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .lib import CcnetError
-from .schedulers import DDPMScheduler
+from .schedulers import DDPMScheduler, _cfg_mode
 
 
 def sample_from_controlnet(controlnet, noisy_e, controlnet_cond, timesteps, prompt_embeds, class_labels=None,
@@ -60,12 +60,18 @@ class Sampler:
     """Batched ControlNet+UNet sampler with CFG; one instance per (controlnet, diffusion, scheduler)."""
 
     def __init__(self, controlnet, diffusion, scheduler, stage1=None, guidance_scale: Optional[float] = None,
-                 conditioning_scale: float = 1.0, scale_factor: float = 0.01, cfg: bool = True):
+                 conditioning_scale: float = 1.0, scale_factor: float = 0.01, cfg: bool = True,
+                 use_graph: bool = True):
         self.controlnet, self.diffusion, self.scheduler, self.stage1 = controlnet, diffusion, scheduler, stage1
         self.guidance_scale = guidance_scale
         self.conditioning_scale = conditioning_scale
         self.scale_factor = scale_factor
         self.cfg = cfg  # run the [uncond, text] double batch as the reference does (run_controlnet_inference.py:219)
+        # One denoising step is ~500 kernel launches; enqueued one by one from Python the host, not the GPU, sets the
+        # pace.  With use_graph the step is captured once per input geometry into a HIP graph (static latent /
+        # timestep / coefficient buffers) and replayed for every timestep.
+        self.use_graph = use_graph
+        self._graphs = {}
 
     @torch.no_grad()
     def prepare(self, cond: torch.Tensor, prompt_embeds: torch.Tensor, empty_prompt_embeds: torch.Tensor,
@@ -108,20 +114,95 @@ class Sampler:
             return self.scheduler.step(out, t, x, noise=ddpm_noise)
         return self.scheduler.step(out, t, x)
 
+    # ------------------------------------------------------------------ HIP-graph replay of the denoising step
+    def _static_step(self, g):
+        """The step on static buffers: ControlNet -> UNet -> fused CFG + scheduler update of g["x"] in place."""
+        st = g["st"]
+        down, mid = self.controlnet.forward_native(
+            g["x"], g["ts"], None, self.conditioning_scale, class_labels=st["cls"], _ctx_kv=st["kv_c"],
+            _cond_emb=st["cond_emb"], _x_batch=st["Bc"])
+        out = self.diffusion(g["x"], g["ts"], class_labels=st["cls"], down_block_additional_residuals=down,
+                             mid_block_additional_residual=mid, _ctx_kv=st["kv_u"], _x_batch=st["Bc"])
+        if self.cfg:
+            mode, gs = _cfg_mode(self.guidance_scale)
+        else:
+            mode, gs = 3, 0.0
+        ops.cfg_scheduler_step(out, mode, gs, g["coef"], g["x"], noise=g["noise"])
+
+    @staticmethod
+    def _copy_state(dst, src):
+        """Copy the per-batch step-invariant tensors of `src` into the static buffers the graph was captured on."""
+        for k in ("kv_c", "kv_u"):
+            for d, s_ in zip(dst[k][0], src[k][0]):
+                d.copy_(s_)
+        dst["cond_emb"].t.copy_(src["cond_emb"].t)
+        if src["cls"] is not None:
+            dst["cls"].copy_(src["cls"])
+
+    def _graph_for(self, st, x: torch.Tensor, ddpm: bool):
+        key = (tuple(x.shape), st["Bc"], st["cls"] is None, st["kv_c"][1], ddpm, id(self.scheduler),
+               tuple(int(t) for t in self.scheduler.timesteps[:2]), len(self.scheduler.timesteps))
+        g = self._graphs.get(key)
+        if g is not None:
+            self._copy_state(g["st"], st)
+            return g
+        dev = x.device
+        ts_host = [float(t) for t in self.scheduler.timesteps]
+        g = {"st": st, "x": x.clone(), "ts": torch.zeros(1, dtype=torch.float32, device=dev),
+             "coef": torch.zeros(8, dtype=torch.float32, device=dev),
+             "noise": torch.zeros_like(x) if ddpm else None,
+             "ts_table": torch.tensor(ts_host, dtype=torch.float32, device=dev).reshape(-1, 1),
+             "coef_table": torch.stack([self.scheduler.coef_tensor(int(t), dev) for t in self.scheduler.timesteps])}
+        g["ts"].copy_(g["ts_table"][0])
+        g["coef"].copy_(g["coef_table"][0])
+        self._static_step(g)  # eager once: weight packing, kernel attributes and allocator warm-up stay out of the graph
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_step(g)
+        g["graph"] = graph
+        self._graphs[key] = g
+        return g
+
+    def _sample_graphed(self, st, noise, ddpm_noise, record_latents, max_steps):
+        ddpm = isinstance(self.scheduler, DDPMScheduler)
+        x0 = noise.float().contiguous()
+        g = self._graph_for(st, x0, ddpm)
+        g["x"].copy_(x0)
+        trace = []
+        for i, t in enumerate(self.scheduler.timesteps):
+            if max_steps is not None and i >= max_steps:
+                break
+            g["ts"].copy_(g["ts_table"][i])
+            g["coef"].copy_(g["coef_table"][i])
+            if ddpm:
+                if int(t) > 0:
+                    n = ddpm_noise[i] if ddpm_noise is not None else torch.randn(x0.shape, dtype=torch.float32)
+                    g["noise"].copy_(n.to(x0.device, non_blocking=True))
+                else:
+                    g["noise"].zero_()  # sigma is 0 at t = 0: upstream adds no noise there
+            g["graph"].replay()
+            if record_latents:
+                trace.append(g["x"].clone())
+        return g["x"].clone(), trace
+
     @torch.no_grad()
     def sample(self, noise: torch.Tensor, cond: torch.Tensor, prompt_embeds: torch.Tensor,
                empty_prompt_embeds: torch.Tensor, acquisition_time: Optional[torch.Tensor] = None,
                ddpm_noise: Optional[List[torch.Tensor]] = None, record_latents: bool = False,
                max_steps: Optional[int] = None, decode: bool = True):
         st = self.prepare(cond, prompt_embeds, empty_prompt_embeds, acquisition_time)
-        x = noise.float().contiguous()
-        trace = []
-        for i, t in enumerate(self.scheduler.timesteps):
-            if max_steps is not None and i >= max_steps:
-                break
-            x, _ = self.step(st, x, int(t), None if ddpm_noise is None else ddpm_noise[i])
-            if record_latents:
-                trace.append(x.clone())
+        if self.use_graph and not ops.prof_is_enabled():
+            x, trace = self._sample_graphed(st, noise, ddpm_noise, record_latents, max_steps)
+        else:
+            x = noise.float().contiguous()
+            trace = []
+            for i, t in enumerate(self.scheduler.timesteps):
+                if max_steps is not None and i >= max_steps:
+                    break
+                x, _ = self.step(st, x, int(t), None if ddpm_noise is None else ddpm_noise[i])
+                if record_latents:
+                    trace.append(x.clone())
         res = {"latent": x}
         if record_latents:
             res["latents"] = trace
