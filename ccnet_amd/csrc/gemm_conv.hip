@@ -44,6 +44,8 @@ struct ConvArgs {
     float scale;
     int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
     long long sx1, sw, so;
+    int splitk;   // > 1: blockIdx.y selects a K slice, raw fp32 partial sums go to ws[slice][M][Cout]
+    float* ws;
     unsigned x1_bytes, x2_bytes, w_bytes;
 #ifdef CCNET_STAMP
     unsigned long long* dbg;  // diagnostic build only: per-block phase time stamps
@@ -61,7 +63,7 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wa
 // GEGLU = true: the packed weight rows interleave 32-row blocks of the "a" half and the "gate" half of an
 // MLPBlock(act="GEGLU").linear1, so accumulators (2p, j) and (2p+1, j) of a wave hold a and gate of the same
 // outputs in the same lane/register; the epilogue writes a * gelu_erf(gate) (Cout/2 columns).
-template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK>
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK, bool SPLIT>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int NT = 64 * WM * WN, BM = 32 * TJ * WM, BN = 32 * TI * WN;
     static_assert(BK == 64 || BK == 32, "K-step of 64 or 32 channels");
@@ -139,7 +141,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     };
 
     // K-step being fetched: (tap_n, cc_n) and its flat index kt_n; slices [lo, hi) of its NL DMA instructions
-    int tap_n = 0, cc_n = 0, kt_n = 0;
+    // split-K: this block accumulates K-steps [kt_lo, kt_lo + KTl) of the a.KT steps
+    const int slice = SPLIT ? blockIdx.y : 0;
+    const int kt_lo = SPLIT ? (int)((long long)a.KT * slice / a.splitk) : 0;
+    const int KTl = SPLIT ? (int)((long long)a.KT * (slice + 1) / a.splitk) - kt_lo : a.KT;
+    int tap_n = kt_lo / a.CT, cc_n = kt_lo - tap_n * a.CT, kt_n = kt_lo;
     auto issue_slice = [&](int s, int lo, int hi) {
         char* xb = smem + s * STAGE + wave * 1024;
         char* wb = xb + BM * RB;
@@ -175,13 +181,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         for (int q = 0; q < 4; ++q) {
             const int nb = n0 + wn * 32 * TI + i * 32 + 8 * q + 4 * hh;
             f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias && nb < a.Cout) bq = *(const f32x4*)(a.bias + nb);
+            if (!SPLIT && a.bias && nb < a.Cout) bq = *(const f32x4*)(a.bias + nb);  // split-K: added by the reduce pass
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bq[e];
         }
-    if (!GEGLU && a.rowvec) {  // (the host rejects act = 2 with a time-embedding row)
+    if (!GEGLU && !SPLIT && a.rowvec) {  // (the host rejects act = 2 with a time-embedding row)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int m = m0 + wm * 32 * TJ + j * 32 + l31;
@@ -210,23 +216,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     // step kt-1, which every wave has left before it passed that step's barrier.
     static_assert(NS >= 2 && NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
     STAMP(1);
-    set_tap(0);
+    set_tap(tap_n);
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p) {
-        if (p < a.KT) {
+        if (p < KTl) {
             if (p > 0 && cc_n == 0) set_tap(tap_n);
             issue_slice(p, 0, NL);
             advance();
         }
     }
-    if (a.KT >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (NS - 2)) : "memory");
+    if (KTl >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (NS - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     STAMP(2);
     int s = 0, sn = NS - 1;  // stage being read, stage being refilled
-    for (int kt = 0; kt < a.KT; ++kt) {
-        const bool more = kt + NS - 1 < a.KT;
+    for (int kt = 0; kt < KTl; ++kt) {
+        const bool more = kt + NS - 1 < KTl;
         const char* xb = smem + s * STAGE;
         const char* wb = xb + BM * RB;
         if (more && cc_n == 0) set_tap(tap_n);
@@ -266,6 +272,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     __bf16* outp = a.out + (long long)z * a.so;
     const int cout_out = GEGLU ? a.Cout / 2 : a.Cout;
     const int ncol0 = (GEGLU ? n0 / 2 + wn * 16 * TI : n0 + wn * 32 * TI) + 8 * hh;
+    if constexpr (SPLIT) {
+        // raw fp32 partial sums, 16 B per lane (4 consecutive couts of its pixel); ccnet's reduce kernel sums the
+        // slices in slice order and applies the epilogue, so results do not depend on the launch geometry
+        float* wsl = a.ws + (long long)slice * a.M * a.Cout;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = m0 + wm * 32 * TJ + j * 32 + l31;
+            if (m < a.M) {
+                float* wrow = wsl + (long long)m * a.Cout + n0 + wn * 32 * TI + 4 * hh;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (n0 + wn * 32 * TI + i * 32 + 8 * q + 4 * hh < a.Cout)
+                            *(f32x4*)(wrow + i * 32 + 8 * q) =
+                                f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    }
+            }
+        }
+        STAMP(4);
+        return;
+    }
+    if constexpr (!SPLIT) {
     auto swap32 = [](unsigned& lo, unsigned& hi) {
         const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
         lo = r[0]; hi = r[1];
@@ -374,7 +403,58 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
             }
         }
     }
+    }  // !SPLIT
     STAMP(4);
+}
+
+// split-K second pass: out = scale * act(bias + time-embedding row + sum over slices) + res1 (and out2 = that + res2).
+// 8 columns per thread, slices summed in index order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
+    const int cpr = a.Cout / 8;
+    const long long total = (long long)a.M * cpr;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx / cpr), c = (int)(idx - (long long)m * cpr) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (a.bias) {
+            const f32x4 b0 = *(const f32x4*)(a.bias + c), b1 = *(const f32x4*)(a.bias + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = b0[e]; v[4 + e] = b1[e]; }
+        }
+        if (a.rowvec) {
+            const float* rv = a.rowvec + (long long)(m / a.HWout) * a.ld_rowvec + c;
+            const f32x4 t0 = *(const f32x4*)rv, t1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+        }
+        for (int sl = 0; sl < a.splitk; ++sl) {
+            const float* wp = a.ws + ((long long)sl * a.M + m) * a.Cout + c;
+            const f32x4 p0 = *(const f32x4*)wp, p1 = *(const f32x4*)(wp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+        }
+        if (a.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= a.scale;
+        if (a.res1) {
+            float r[8];
+            unpack8(*(const u32x4*)(a.res1 + (long long)m * a.ldres1 + c), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        *(u32x4*)(a.out + (long long)m * a.ldo + c) = pack8(v);
+        if (a.out2) {
+            float r[8];
+            unpack8(*(const u32x4*)(a.res2 + (long long)m * a.ldres2 + c), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            *(u32x4*)(a.out2 + (long long)m * a.ldo2 + c) = pack8(v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- profiling hooks
@@ -384,19 +464,20 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 
 int g_force_cfg = -1;  // tuning: force a tile configuration (index into the dispatch below)
+int g_force_splitk = 0;  // tuning: force the split-K factor (0 = heuristic)
 int g_order = -1;     // tuning: force the tile order (0 N-fastest, 1 M-fastest, -1 = heuristic)
 #ifdef CCNET_STAMP
 unsigned long long* g_dbg = nullptr;
 #endif
 int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, bit1 = w descriptor empty
 
-template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64>
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK>,
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set = true;
@@ -406,49 +487,48 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     b.tilesN = (a.Cout + BN - 1) / BN;
     b.tilesM = (a.M + BM - 1) / BM;
     b.tiles = b.tilesM * b.tilesN;
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK>), dim3(b.tiles, 1, batch), dim3(NT), LDS, st, b);
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT>), dim3(b.tiles, SPLIT ? b.splitk : 1, batch),
+                       dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
+    if (SPLIT) {
+        const long long items = (long long)b.M * (b.Cout / 8);
+        const int grid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, b);
+        CCNET_LAUNCH_CHECK();
+    }
     return CCNET_OK;
 }
 
 typedef int (*LaunchFn)(const ConvArgs&, int, hipStream_t);
-struct TileCfg { int bm, bn; LaunchFn fn, fn_geglu; };
+struct TileCfg { int bm, bn; LaunchFn fn, fn_geglu, fn_split; };
+// Indices are stable (tools/bench_conv.py --cfgs): entries that lost every measurement were removed and stay empty.
 const TileCfg kCfgs[] = {
-    {128, 128, launch<2, 2, 2, 2, false>, launch<2, 2, 2, 2, true>},   // 0
-    {128, 64, launch<2, 1, 2, 2, false>, launch<2, 1, 2, 2, true>},    // 1
-    {64, 64, launch<1, 1, 2, 2, false>, launch<1, 1, 2, 2, true>},     // 2
-    {128, 320, launch<2, 2, 2, 5, false>, nullptr},                     // 3: Cout = 320 without tile waste
-    {128, 256, launch<2, 2, 2, 4, false>, nullptr},                     // 4
-    {256, 128, launch<2, 2, 4, 2, false>, nullptr},                     // 5
-    {256, 256, launch<2, 2, 4, 4, false>, launch<2, 2, 4, 4, true>},   // 6
-    {64, 128, launch<1, 2, 2, 2, false>, nullptr},                      // 7
-    {64, 256, launch<1, 2, 2, 4, false>, nullptr},                      // 8
-    {256, 64, launch<4, 1, 2, 2, false>, nullptr},                      // 9
-    {256, 256, launch<4, 2, 2, 4, false>, nullptr},                     // 10: 8 waves
-    {256, 128, launch<4, 2, 2, 2, false>, nullptr},                     // 11: 8 waves
-    {128, 160, launch<2, 1, 2, 5, false>, nullptr},                     // 12: 2 waves
-    {128, 128, launch<2, 2, 2, 2, false, 3>, launch<2, 2, 2, 2, true, 3>},   // 13: 3 stages
-    {128, 128, launch<2, 2, 2, 2, false, 4>, nullptr},                  // 14: 4 stages
-    {256, 128, launch<4, 2, 2, 2, false, 3>, nullptr},                  // 15: 8 waves, 3 stages
-    {128, 64, launch<2, 1, 2, 2, false, 3>, nullptr},                   // 16: 2 waves, 3 stages
-    {128, 256, launch<2, 2, 2, 4, false, 3>, nullptr},                  // 17: 3 stages
-    {256, 256, launch<4, 2, 2, 4, false, 2>, nullptr},                  // 18: = 10
-    {128, 128, launch<4, 2, 1, 2, false, 3>, nullptr},                  // 19: 8 waves (32 x 64 per wave), 3 stages
-    {256, 256, launch<4, 2, 2, 4, false, 4, 32>, launch<4, 2, 2, 4, true, 4, 32>},  // 20: 8 waves, 4 x 32-deep stages
-    {256, 128, launch<4, 2, 2, 2, false, 4, 32>, launch<4, 2, 2, 2, true, 4, 32>},  // 21
-    {128, 128, launch<2, 2, 2, 2, false, 4, 32>, launch<2, 2, 2, 2, true, 4, 32>},  // 22: 64 KB, two blocks per CU
-    {256, 320, launch<4, 2, 2, 5, false, 2>, nullptr},                  // 23: 8 waves
-    {128, 256, launch<2, 4, 2, 2, false, 3>, nullptr},                  // 24: 8 waves, 3 stages
-    {256, 128, launch<4, 2, 2, 2, false, 6, 32>, nullptr},              // 25: 6 x 32-deep (144 KB)
-    {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>},  // 26: 4 waves, 72 KB: two blocks per CU
-    {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr},              // 27: 4 waves, 57 KB: two blocks per CU
-    {128, 128, launch<2, 2, 2, 2, false, 3, 32>, launch<2, 2, 2, 2, true, 3, 32>},  // 28: 48 KB: three blocks per CU
-    {256, 256, launch<4, 2, 2, 4, false, 2, 32>, launch<4, 2, 2, 4, true, 2, 32>},  // 29: 8 waves, 64 KB: two blocks per CU if registers allow
+    {128, 128, launch<2, 2, 2, 2, false>, launch<2, 2, 2, 2, true>, nullptr},   // 0: 4 waves, two blocks per CU
+    {128, 64, launch<2, 1, 2, 2, false>, launch<2, 1, 2, 2, true>, nullptr},    // 1: 2 waves
+    {64, 64, launch<1, 1, 2, 2, false>, launch<1, 1, 2, 2, true>, nullptr},     // 2: 1 wave, tiny problems
+    {128, 320, launch<2, 2, 2, 5, false>, nullptr, nullptr},                     // 3: 4 waves, Cout = 320 without waste
+    {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},  // 4-6
+    {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},  // 7-9
+    {256, 256, launch<4, 2, 2, 4, false>, nullptr, nullptr},                     // 10: 8 waves, 2 x 64-deep stages
+    {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 11-12
+    {128, 128, launch<2, 2, 2, 2, false, 3>, nullptr, nullptr},                  // 13: 4 waves, 3 stages
+    {0, 0, nullptr, nullptr, nullptr},                                           // 14
+    {256, 128, launch<4, 2, 2, 2, false, 3>, nullptr, nullptr},                  // 15: 8 waves, 3 stages
+    {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},  // 16-18
+    {128, 128, launch<4, 2, 1, 2, false, 3>, nullptr, launch<4, 2, 1, 2, false, 3, 64, true>},  // 19: 8 waves, 3 stages
+    {256, 256, launch<4, 2, 2, 4, false, 4, 32>, launch<4, 2, 2, 4, true, 4, 32>, nullptr},    // 20: 8 waves, 4 x 32-deep
+    {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 21-22
+    {256, 320, launch<4, 2, 2, 5, false, 2>, nullptr, launch<4, 2, 2, 5, false, 2, 64, true>},  // 23: 8 waves
+    {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 24-25
+    {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>, nullptr},    // 26: 4 waves, 72 KB
+    {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr, nullptr},              // 27: 4 waves, 57 KB
+    {128, 128, launch<2, 2, 2, 2, false, 3, 32>, nullptr, nullptr},              // 28: 48 KB: three blocks per CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int pick_cfg(int M, int Cout, int K, int batch, bool geglu) {
-    if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (!geglu || kCfgs[g_force_cfg].fn_geglu)) return g_force_cfg;
+    if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (geglu ? kCfgs[g_force_cfg].fn_geglu : kCfgs[g_force_cfg].fn))
+        return g_force_cfg;
     auto blocks = [&](int c) {
         return (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((Cout + kCfgs[c].bn - 1) / kCfgs[c].bn) * batch;
     };
@@ -479,6 +559,7 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 0) { g_force_cfg = value; return CCNET_OK; }  // force conv tile configuration (-1 = heuristic)
     if (key == 1) { g_dbg_zero = value; return CCNET_OK; }
     if (key == 2) { g_order = value; return CCNET_OK; }
+    if (key == 3) { g_force_splitk = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
@@ -531,6 +612,34 @@ extern "C" int ccnet_prof_shapes(double* table, int max_rows) {
         table[7 * j + 6] += t;
     }
     return n;
+}
+
+namespace {
+// split-K plan: deep-K layers whose 256x320 tiling leaves most CUs idle (M <= 8192 at Cout 1280) run S K-slices per
+// tile and a reduce pass.  Returns S (1 = no split) for the tile configuration `cfg`.
+int plan_splitk(const ccnet_conv_params* p, int M, int KT, int batch, int* cfg) {
+    if (p->act == 2 || batch > 1) return 1;
+    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((p->Cout + bn - 1) / bn); };
+    int S = 1;
+    if (g_force_splitk > 0) {
+        S = g_force_splitk;
+    } else if ((p->Cout % 320) == 0 && tiles(256, 320) < 200) {
+        S = (int)(256 / tiles(256, 320));
+        if (S > 8) S = 8;
+    }
+    while (S > 1 && KT / S < 12) --S;  // every slice keeps a real K loop
+    if (S > 1 && (*cfg < 0 || !kCfgs[*cfg].fn_split)) *cfg = 23;  // the tile the split is planned for
+    return S;
+}
+}  // namespace
+
+extern "C" size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p) {
+    if (!p || p->C1 <= 0 || p->Cout <= 0 || p->N <= 0) return 0;
+    const int KT = p->R * p->R * ((p->C1 + p->C2) / 64);
+    const int M = p->N * p->Hout * p->Wout;
+    int cfg = -1;
+    const int S = plan_splitk(p, M, KT, p->batch > 1 ? p->batch : 1, &cfg);
+    return S > 1 ? (size_t)S * M * p->Cout * sizeof(float) : 0;
 }
 
 extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
@@ -599,8 +708,14 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
         (void)hipEventRecord(rec->e0, st);
     }
     const bool geglu = p->act == 2;
-    const TileCfg& cfg = kCfgs[pick_cfg(a.M, p->Cout, a.KT * 64, batch, geglu)];
-    const int rc = geglu ? cfg.fn_geglu(a, batch, st) : cfg.fn(a, batch, st);
+    int cfg_i = pick_cfg(a.M, p->Cout, a.KT * 64, batch, geglu);
+    a.splitk = plan_splitk(p, a.M, a.KT, batch, &cfg_i);
+    if (a.splitk > 1) {
+        if (!p->workspace || p->workspace_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return CCNET_EWS;
+        a.ws = (float*)p->workspace;
+    }
+    const TileCfg& cfg = kCfgs[cfg_i];
+    const int rc = a.splitk > 1 ? cfg.fn_split(a, batch, st) : geglu ? cfg.fn_geglu(a, batch, st) : cfg.fn(a, batch, st);
     if (rec) (void)hipEventRecord(rec->e1, st);
     return rc;
 }

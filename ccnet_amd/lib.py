@@ -20,7 +20,7 @@ EXPORTS = [
     "ccnet_geglu_bf16", "ccnet_attention_d64_bf16", "ccnet_softmax_rows_bf16", "ccnet_timestep_embedding",
     "ccnet_linear_f32", "ccnet_cfg_scheduler_step", "ccnet_nchw_f32_to_nhwc_bf16", "ccnet_nhwc_bf16_to_nchw_f32",
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
-    "ccnet_set_option", "ccnet_prof_shapes",
+    "ccnet_set_option", "ccnet_prof_shapes", "ccnet_conv_workspace_bytes",
 ]
 
 
@@ -39,7 +39,8 @@ class ConvParams(C.Structure):
         ("ldx1", C.c_int32), ("ldx2", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldo2", C.c_int32),
         ("ldres1", C.c_int32), ("ldres2", C.c_int32), ("ld_rowvec", C.c_int32),
         ("act", C.c_int32), ("scale", C.c_float), ("batch", C.c_int32),
-        ("sx1", C.c_int64), ("sw", C.c_int64), ("so", C.c_int64), ("reserved", C.c_int32 * 4),
+        ("sx1", C.c_int64), ("sw", C.c_int64), ("so", C.c_int64), ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -61,6 +62,8 @@ def load() -> C.CDLL:
     lib.ccnet_version.restype = i
     lib.ccnet_arch.restype = C.c_char_p
     lib.ccnet_conv_gemm_bf16.argtypes = [C.POINTER(ConvParams), vp]
+    lib.ccnet_conv_workspace_bytes.argtypes = [C.POINTER(ConvParams)]
+    lib.ccnet_conv_workspace_bytes.restype = sz
     lib.ccnet_conv_in_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, vp, i, i, vp, i, i, i, vp]
     lib.ccnet_conv_out_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, vp, vp]
     lib.ccnet_groupnorm_workspace_bytes.restype = sz

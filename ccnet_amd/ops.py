@@ -92,6 +92,11 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
         raise _l.CcnetError("res1 rows mismatch")
     if rowvec is not None and (rowvec.shape[0] != x.N or rowvec.shape[1] < Cout or rowvec.dtype != torch.float32):
         raise _l.CcnetError("rowvec must be fp32 [N, >=Cout]")
+    wsb = lib.ccnet_conv_workspace_bytes(C.byref(p))
+    ws = None
+    if wsb:
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.t.device)  # split-K partial sums
+        p.workspace = ws.data_ptr(); p.workspace_bytes = wsb
     _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "conv_gemm")
     return (out, out2) if out2 is not None else out
 

@@ -69,10 +69,14 @@ typedef struct ccnet_conv_params {
     float scale;
     int32_t batch;        /* >1: batched plain GEMM (R==1); z-th problem uses the strides below */
     int64_t sx1, sw, so;  /* element strides between batch problems for x1, w, out              */
-    int32_t reserved[4];
+    void* workspace;      /* fp32 scratch for split-K partial sums, ccnet_conv_workspace_bytes(p) bytes (may be 0) */
+    int64_t workspace_bytes;
 } ccnet_conv_params;
 
 int ccnet_conv_gemm_bf16(const ccnet_conv_params* p /*host*/, void* stream);
+/* Deep-K layers with few output tiles are split along K (partial sums in `workspace`, summed in slice order by a second
+ * launch): bytes the caller must provide for this problem, 0 if it runs unsplit. */
+size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p /*host*/);
 
 /* Direct 3x3 convolution for tiny channel counts at the network edges.
  *   conv_in_small : x fp32 NCHW [Nsrc][Cin<=8][H][W] (image n reads x[n % Nsrc]) -> NHWC bf16 [N][Hout][Wout][ldo]

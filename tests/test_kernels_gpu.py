@@ -97,6 +97,38 @@ def test_conv_epilogue_full(cuda):
     _close(_nchw(out2), ref + _nchw(r2), atol=3e-2, what="epilogue out2")
 
 
+def test_conv_split_k(cuda):
+    """Deep-K layer with few output tiles: K slices + reduce pass (workspace from ccnet_conv_workspace_bytes) must
+    give the unsplit result, with the whole epilogue (bias, rowvec, residual, dual output) applied by the reduce."""
+    import ctypes as C
+    from ccnet_amd import lib as _lib
+    ops = _ops()
+    N, H, W, C1, C2, Cout = 2, 16, 16, 640, 640, 320   # M = 512, K = 11520: 2 tiles of 256x320
+    x1 = _rand_act(N, H, W, C1, cuda, 11)
+    x2 = _rand_act(N, H, W, C2, cuda, 12)
+    r1 = _rand_act(N, H, W, Cout, cuda, 13)
+    r2 = _rand_act(N, H, W, Cout, cuda, 14)
+    g = torch.Generator().manual_seed(15)
+    Cin = C1 + C2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(N, Cout, generator=g).to(cuda)
+    wp = _pack_w(w).to(cuda)
+    l = _lib.load()
+    l.ccnet_set_option(3, 1)   # forced unsplit
+    o_ref, o2_ref = ops.conv(x1, wp, b.to(cuda), Cout, R=3, x2=x2, rowvec=rv, scale=0.9, res1=r1, res2=r2)
+    for S in (0, 3, 8):        # heuristic (splits this shape), forced 3 and 8 slices
+        l.ccnet_set_option(3, S)
+        out, out2 = ops.conv(x1, wp, b.to(cuda), Cout, R=3, x2=x2, rowvec=rv, scale=0.9, res1=r1, res2=r2)
+        _close(out.t.float(), o_ref.t.float(), atol=2e-2, what=f"split-K {S} out")
+        _close(out2.t.float(), o2_ref.t.float(), atol=3e-2, what=f"split-K {S} out2")
+    l.ccnet_set_option(3, 0)
+    ref = F.conv2d(torch.cat([_nchw(x1), _nchw(x2)], 1), wp.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2),
+                   b.to(cuda), padding=1)
+    ref = (ref + rv[:, :, None, None]) * 0.9 + _nchw(r1)
+    _close(_nchw(out), ref, atol=2e-2, what="split-K vs conv2d")
+
+
 def test_gemm_batched(cuda):
     ops = _ops()
     Bt, M, Nn, K = 3, 100, 72, 128

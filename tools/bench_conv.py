@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--filter", type=str, default="")
     ap.add_argument("--cfgs", type=str, default="-1", help="comma list of forced tile configs (-1 = heuristic)")
     ap.add_argument("--dbg-zero", type=int, default=0)
+    ap.add_argument("--splitk", type=int, default=0, help="force the split-K factor (0 = heuristic)")
     ap.add_argument("--order", type=int, default=-1, help="force tile order: 0 N-fastest, 1 M-fastest")
     ap.add_argument("--cold", action="store_true", help="rotate over 12 weight copies so weights come from HBM")
     args = ap.parse_args()
@@ -60,6 +61,7 @@ def main():
         from ccnet_amd import lib
         lib.load().ccnet_set_option(1, args.dbg_zero)
     _lib.load().ccnet_set_option(2, args.order)
+    _lib.load().ccnet_set_option(3, args.splitk)
     dev = torch.device("cuda:0")
     tot_f, tot_t = 0.0, 0.0
     for shape in SHAPES:
