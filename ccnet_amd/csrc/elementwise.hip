@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = b0[e]; v[4 + e] = b1[e]; }
         }
-#pragma unroll
+        // one input channel (9 taps, 18 ds_read_b128) per trip: fully unrolled over CIN the weight fragments alone
+        // exceed the register file and hipcc spills
+#pragma unroll 1
         for (int c = 0; c < CIN; ++c)
 #pragma unroll
             for (int kr = 0; kr < 3; ++kr)
