@@ -171,9 +171,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
     };
 
+    const int swz = swz_of(l31);
+    const int xrow_off = (wm * 32 * TJ + l31) * RB, wrow_off = (wn * 32 * TI + l31) * RB;
+
+    // NS-stage ring, prefetch distance NS-1 K-steps: step kt's MFMAs run while the DMAs of steps kt+1 .. kt+NS-1 are in
+    // flight.  The wait that ends a step is COUNTED (all but the newest NS-2 steps' DMAs retired) and the barrier is
+    // a raw s_barrier, so loads stay in flight across it; the stage refilled during step kt is the one read during
+    // step kt-1, which every wave has left before it passed that step's barrier.
+    static_assert(NS >= 2 && NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
+    STAMP(1);
+    set_tap(tap_n);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) {
+        if (p < KTl) {
+            if (p > 0 && cc_n == 0) set_tap(tap_n);
+            issue_slice(p, 0, NL);
+            advance();
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the first stages' DMAs are in flight before the accumulator-init loads go out
     // Accumulators start at bias[cout] (+ the image's time-embedding row): register (i, j, 4q + e) of a lane is cout
     // n0 + wn*32*TI + 32 i + 8 q + 4 hh + e of pixel m0 + wm*32*TJ + 32 j + l31, so the epilogue has no column-indexed
-    // operand left and these loads complete under the first tile's DMA latency.
+    // operand left and these loads (issued after the first stages' DMAs) complete under the first tile's DMA latency.
     f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -207,24 +226,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         }
     }
 
-    const int swz = swz_of(l31);
-    const int xrow_off = (wm * 32 * TJ + l31) * RB, wrow_off = (wn * 32 * TI + l31) * RB;
-
-    // NS-stage ring, prefetch distance NS-1 K-steps: step kt's MFMAs run while the DMAs of steps kt+1 .. kt+NS-1 are in
-    // flight.  The wait that ends a step is COUNTED (all but the newest NS-2 steps' DMAs retired) and the barrier is
-    // a raw s_barrier, so loads stay in flight across it; the stage refilled during step kt is the one read during
-    // step kt-1, which every wave has left before it passed that step's barrier.
-    static_assert(NS >= 2 && NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
-    STAMP(1);
-    set_tap(tap_n);
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p) {
-        if (p < KTl) {
-            if (p > 0 && cc_n == 0) set_tap(tap_n);
-            issue_slice(p, 0, NL);
-            advance();
-        }
-    }
     if (KTl >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL * (NS - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
