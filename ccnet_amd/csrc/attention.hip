@@ -210,9 +210,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
     }
 }
 
-// ------------------------------------------------------------------ row softmax (generic-d fallback)
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const __bf16* x, int ldx, int rows, int cols, float scale,
-                                                           __bf16* out, int ldo) {
+// ------------------------------------------------------------------ generic-head-dim fallback pieces
+// row softmax over `cols` columns; columns [cols, cols_pad) are written as zeros so the probabilities can feed a
+// GEMM whose K is padded to a multiple of 64
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const __bf16* x, int ldx, int rows, int cols, int cols_pad,
+                                                           float scale, __bf16* out, int ldo) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -227,6 +229,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const __bf16* x, int 
     unsigned short* orow = (unsigned short*)(out + (long long)row * ldo);
     for (int c = lane; c < cols; c += 64)
         orow[c] = f32_to_bf16_bits(__expf(bf16_bits_to_f32(xr[c]) * scale - mx) * inv);
+    for (int c = cols + lane; c < cols_pad; c += 64) orow[c] = 0;
+}
+
+// out[z][c][r] = x[z][r][c] for r < rows, 0 for rows <= r < rows_pad  (V^T of the fallback's P.V product)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const __bf16* x, int ldx, int rows, int cols, long long sx,
+                                                            __bf16* out, int ldo, int rows_pad, long long so) {
+    __shared__ unsigned short tile[64][65];
+    const unsigned short* xp = (const unsigned short*)(x + (long long)blockIdx.z * sx);
+    unsigned short* op = (unsigned short*)(out + (long long)blockIdx.z * so);
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? xp[(long long)r * ldx + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows_pad) op[(long long)c * ldo + r] = tile[tx][i];
+    }
 }
 
 }  // namespace
@@ -250,11 +272,22 @@ extern "C" int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, i
     return CCNET_OK;
 }
 
-extern "C" int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, float scale, void* out, int ldo,
-                                       void* stream) {
-    if (!x || !out || rows <= 0 || cols <= 0) return CCNET_EINVAL;
+extern "C" int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, int cols_pad, float scale,
+                                       void* out, int ldo, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || cols_pad < cols || ldo < cols_pad) return CCNET_EINVAL;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x, ldx, rows, cols, scale, (__bf16*)out, ldo);
+                       (const __bf16*)x, ldx, rows, cols, cols_pad, scale, (__bf16*)out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_transpose_pad_bf16(const void* x, int ldx, int rows, int cols, int64_t sx, void* out, int ldo,
+                                        int rows_pad, int64_t so, int batch, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || rows_pad < rows || ldo < rows_pad || batch <= 0 || batch > 65535)
+        return CCNET_EINVAL;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64, batch), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)x, ldx, rows, cols, (long long)sx, (__bf16*)out, ldo,
+                       rows_pad, (long long)so);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

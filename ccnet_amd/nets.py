@@ -354,20 +354,24 @@ class _Trunk(nn.Module):
     def _run_attn(self, pk, a, x: Act, kv: torch.Tensor, S: int, res2: Optional[Act] = None):
         p = pk["att"][id(a)]
         C_, inner, heads, hc = x.C, p["inner"], p["heads"], p["head_ch"]
-        if hc != 64:
-            raise CcnetError(f"attention head dim {hc}: only num_head_channels == 64 is lowered to the flash kernel "
-                             "in this round (SD-2.1 geometry); see DESIGN.md 'out of scope'")
         B, T = x.N, x.H * x.W
         scale = 1.0 / math.sqrt(hc)
+        if hc % 64:
+            raise CcnetError(f"attention head dim {hc}: the MI355X lowering needs num_head_channels % 64 == 0")
+
+        def attend(q, k, v, Skv):
+            if hc == 64:  # flash kernel (SD-2.1 geometry)
+                return ops.attention_d64(q, k, v, B, heads, T, Skv, scale)
+            return ops.attention_generic(q, k, v, B, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
         h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.norm_eps, False)
         t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
         n1 = ops.layernorm(t, inner, *p["ln1"])
         qkv = ops.linear(n1, p["qkv1"], None, 3 * inner, inner)
-        o = ops.attention_d64(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, heads, T, T, scale)
+        o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
         t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
         n2 = ops.layernorm(t, inner, *p["ln2"])
         q = ops.linear(n2, p["q2"], None, inner, inner)
-        o = ops.attention_d64(q, kv[:, :inner], kv[:, inner:], B, heads, T, S, scale)
+        o = attend(q, kv[:, :inner], kv[:, inner:], S)
         t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
         n3 = ops.layernorm(t, inner, *p["ln3"])
         gl = ops.linear(n3, p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)  # linear1 + GEGLU in one kernel

@@ -177,12 +177,54 @@ def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: 
     return o
 
 
-def softmax_rows(x2d: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
+def softmax_rows(x2d: torch.Tensor, cols: int, scale: float, cols_pad: Optional[int] = None) -> torch.Tensor:
+    """Row softmax of scale * x over the first `cols` columns, in place capable; [cols, cols_pad) is zero-filled."""
     lib = _l.load()
     out = torch.empty_like(x2d)
-    _l.check(lib.ccnet_softmax_rows_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], cols, scale, out.data_ptr(),
-                                         out.stride(0), _stream()), "softmax_rows")
+    _l.check(lib.ccnet_softmax_rows_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], cols, cols_pad or cols, scale,
+                                         out.data_ptr(), out.stride(0), _stream()), "softmax_rows")
     return out
+
+
+def attention_generic(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int, d: int,
+                      scale: float) -> torch.Tensor:
+    """Attention for head dims the flash kernel does not cover (d % 64 == 0, e.g. one head of 512 / 768 channels):
+    scores = scale * Q.K^T (batched MFMA GEMM) -> row softmax -> P.V (batched MFMA GEMM on V^T).  The scores are
+    materialised in bf16, as the reference materialises them in fp16 (CrossAttention._attention)."""
+    lib = _l.load()
+    _need_cuda(q, k, v)
+    if d % 64:
+        raise _l.CcnetError(f"attention head dim {d} is not a multiple of 64")
+    dev = q.device
+    Sp = (Skv + 63) // 64 * 64  # K of the P.V product
+    o = torch.empty((B * Sq, H * d), dtype=BF16, device=dev)
+    kp = torch.zeros((B, Sp, d), dtype=BF16, device=dev)  # zero rows beyond Skv: their scores are masked by the softmax
+    vt = torch.empty((B, d, Sp), dtype=BF16, device=dev)
+    scores = torch.empty((B, Sq, Sp), dtype=BF16, device=dev)
+    for h in range(H):
+        qh, kh, vh = q[:, h * d:(h + 1) * d], k[:, h * d:(h + 1) * d], v[:, h * d:(h + 1) * d]
+        kp[:, :Skv].copy_(kh.unflatten(0, (B, Skv)))
+        _l.check(lib.ccnet_transpose_pad_bf16(vh.data_ptr(), vh.stride(0), Skv, d, Skv * vh.stride(0), vt.data_ptr(), Sp,
+                                              Sp, d * Sp, B, _stream()), "transpose_pad")
+        p = _l.ConvParams()  # scores[b] = scale * Q[b] . Kp[b]^T
+        p.x1 = qh.data_ptr(); p.w = kp.data_ptr(); p.out = scores.data_ptr()
+        p.N, p.Hin, p.Win, p.Hout, p.Wout = 1, Sq, 1, Sq, 1
+        p.C1 = d; p.C2 = 0; p.Cout = Sp; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
+        p.ldx1 = qh.stride(0); p.ldw = d; p.ldo = Sp; p.scale = scale; p.batch = B
+        p.sx1 = Sq * qh.stride(0); p.sw = Sp * d; p.so = Sq * Sp
+        _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "attention scores")
+        s2 = scores.view(B * Sq, Sp)
+        _l.check(lib.ccnet_softmax_rows_bf16(s2.data_ptr(), Sp, B * Sq, Skv, Sp, 1.0, s2.data_ptr(), Sp, _stream()),
+                 "softmax_rows")
+        oh = o[:, h * d:(h + 1) * d]
+        p = _l.ConvParams()  # O[b] = P[b] . V[b]  (weights = V^T rows)
+        p.x1 = scores.data_ptr(); p.w = vt.data_ptr(); p.out = oh.data_ptr()
+        p.N, p.Hin, p.Win, p.Hout, p.Wout = 1, Sq, 1, Sq, 1
+        p.C1 = Sp; p.C2 = 0; p.Cout = d; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
+        p.ldx1 = Sp; p.ldw = Sp; p.ldo = o.stride(0); p.scale = 1.0; p.batch = B
+        p.sx1 = Sq * Sp; p.sw = d * Sp; p.so = Sq * o.stride(0)
+        _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "attention P.V")
+    return o
 
 
 def timestep_embedding(t: torch.Tensor, B: int, dim: int, freqs: torch.Tensor) -> torch.Tensor:

@@ -121,9 +121,15 @@ int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo
 int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                              void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream);
 
-/* Row softmax (in place capable), bf16 rows of length `cols` scaled by `scale` before exp; used by the
- * generic-head-dim attention fallback (single head of 512/768 channels in the repo's YAML geometry). */
-int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, float scale, void* out, int ldo, void* stream);
+/* Generic-head-dim attention fallback (single head of 512 / 768 channels in the repo's YAML geometry,
+ * configs/controlnet/controlnet_v1.yaml:11): scores by ccnet_conv_gemm_bf16 (batched, scale in the epilogue), this row
+ * softmax (in place capable; columns [cols, cols_pad) are written as zeros), V^T by ccnet_transpose_pad_bf16
+ * (out[z][c][r] = x[z][r][c], zero for rows <= r < rows_pad), then P.V by ccnet_conv_gemm_bf16 again.
+ * Replaces CrossAttention._attention where the flash kernel's d = 64 does not apply. */
+int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, int cols_pad, float scale, void* out, int ldo,
+                            void* stream);
+int ccnet_transpose_pad_bf16(const void* x, int ldx, int rows, int cols, int64_t sx, void* out, int ldo, int rows_pad,
+                             int64_t so, int batch, void* stream);
 
 /* ------------------------------------------------------------------ K11
  * fp32 embedding path. timestep_embedding: emb[b][0:half]=cos(t_b*freqs), [half:dim]=sin (cos first);

@@ -3,6 +3,9 @@ import torch
 
 TINY = dict(spatial_dims=2, in_channels=4, num_res_blocks=1, num_channels=[64, 128], attention_levels=[True, True],
             with_conditioning=True, cross_attention_dim=64, num_head_channels=64, norm_eps=1e-5)
+# the repo YAML's shape of attention (configs/controlnet/controlnet_v1.yaml:8-11): no attention at level 0, ONE head per level
+TINY_G2 = dict(spatial_dims=2, in_channels=4, num_res_blocks=1, num_channels=[64, 128, 192], attention_levels=[False, True, True],
+               with_conditioning=True, cross_attention_dim=64, num_head_channels=[0, 128, 192], norm_eps=1e-6)
 TINY_CE = dict(conditioning_embedding_in_channels=1, conditioning_embedding_num_channels=[16, 32, 96, 256])
 TINY_VAE = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[64, 128, 128, 128], latent_channels=4,
                 num_res_blocks=1, attention_levels=[False] * 4, with_encoder_nonlocal_attn=False,

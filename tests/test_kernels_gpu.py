@@ -227,12 +227,36 @@ def test_attention_rescale_branch(cuda):
     _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what="attention rescale")
 
 
+@pytest.mark.parametrize("case", [(2, 1, 256, 256, 512), (2, 1, 196, 77, 768), (1, 2, 49, 49, 128)])
+def test_attention_generic_head_dim(cuda, case):
+    """Head dims beyond the flash kernel (repo-YAML geometry: one head of 512 / 768 channels): batched score GEMM ->
+    masked row softmax -> P.V GEMM, against fp32 softmax attention; ragged token counts and the 77-token context."""
+    ops = _ops()
+    B, H, Sq, Skv, d = case
+    g = torch.Generator().manual_seed(57)
+    qkv = torch.randn(B * Sq, 3 * H * d, generator=g).to(torch.bfloat16).to(cuda)
+    kv = torch.randn(B * Skv, 2 * H * d, generator=g).to(torch.bfloat16).to(cuda)
+    q, k, v = qkv[:, : H * d], kv[:, : H * d], kv[:, H * d:]
+    scale = 1.0 / math.sqrt(d)
+    o = ops.attention_generic(q, k, v, B, H, Sq, Skv, d, scale)
+    qf = q.float().reshape(B, Sq, H, d).permute(0, 2, 1, 3)
+    kf = k.float().reshape(B, Skv, H, d).permute(0, 2, 1, 3)
+    vf = v.float().reshape(B, Skv, H, d).permute(0, 2, 1, 3)
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf
+    ref = ref.permute(0, 2, 1, 3).reshape(B * Sq, H * d)
+    _close(o.float(), ref, atol=3e-2, what=f"generic attention {case}")
+
+
 def test_softmax_rows(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(53)
     x = (torch.randn(37, 196, generator=g) * 3).to(torch.bfloat16).to(cuda)
     out = ops.softmax_rows(x, 196, 0.5)
     _close(out.float(), torch.softmax(x.float() * 0.5, -1), atol=2e-3, what="softmax rows")
+    xp = torch.cat([x, torch.full((37, 60), 9.0, dtype=torch.bfloat16, device=cuda)], 1).contiguous()
+    outp = ops.softmax_rows(xp, 196, 0.5, cols_pad=256)   # padded columns come out as zeros
+    _close(outp[:, :196].float(), torch.softmax(x.float() * 0.5, -1), atol=2e-3, what="softmax rows (padded)")
+    assert outp[:, 196:].abs().max().item() == 0.0
 
 
 def test_timestep_embedding_and_linear(cuda):

@@ -41,6 +41,22 @@ def test_unet_forward_tiny(cuda):
     _check(out, ref, "unet tiny")
 
 
+def test_unet_controlnet_single_head_geometry(cuda):
+    """Repo-YAML style geometry (G2): attention only at the deeper levels, one head of C channels per level."""
+    from _common import TINY_G2
+    pc, oc = build_pair("controlnet", {**TINY_G2, **TINY_CE}, 21, cuda)
+    pu, ou = build_pair("unet", TINY_G2, 22, cuda)
+    x, ctx, cond = _inputs(2, cuda, seed=23)
+    t = torch.tensor([640])
+    down, mid = pc(x.to(cuda), t.to(cuda), cond.to(cuda), 1.0, ctx.to(cuda))
+    out = pu(x.to(cuda), t.to(cuda), ctx.to(cuda), None, down, mid)
+    with torch.no_grad():
+        rd, rm = oc(x, t, cond, 1.0, ctx)
+        ref = ou(x, t, ctx, None, rd, rm)
+    _check(mid.float(), rm, "G2-style controlnet mid")
+    _check(out, ref, "G2-style unet + residuals")
+
+
 def test_controlnet_and_unet_with_residuals_tiny(cuda):
     pc, oc = build_pair("controlnet", {**TINY, **TINY_CE}, 2, cuda, acq=True)
     pu, ou = build_pair("unet", TINY, 3, cuda, acq=True)
