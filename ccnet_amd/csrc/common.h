@@ -61,6 +61,24 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_fast(g * 0.70710678118654752f)); }
 
+// a * gelu_erf(g) on two lanes of packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 run two fp32 ops per lane per issue).
+// erfc(|g| / sqrt 2) = exp2(|g| Q(|g|)) with Q a degree-5 fit (tools/fit_gelu.py: max abs error of gelu 3.1e-7 over
+// all fp32 g, at the fp32 evaluation floor), so gelu(g) = max(g, 0) - |g|/2 * exp2(|g| Q(|g|)): one exponential per
+// element, no reciprocal (the two quarter-rate instructions dominated the A&S 7.1.26 form in this epilogue).
+__device__ __forceinline__ f32x2 geglu_pk(f32x2 a, f32x2 g) {
+    const f32x2 ag = {fabsf(g[0]), fabsf(g[1])};
+    f32x2 q = __builtin_elementwise_fma(ag, f32x2{2.9924784e-05f, 2.9924784e-05f}, f32x2{-0.0007398792f, -0.0007398792f});
+    q = __builtin_elementwise_fma(q, ag, f32x2{0.007977478f, 0.007977478f});
+    q = __builtin_elementwise_fma(q, ag, f32x2{-0.053238206f, -0.053238206f});
+    q = __builtin_elementwise_fma(q, ag, f32x2{-0.45891568f, -0.45891568f});
+    q = __builtin_elementwise_fma(q, ag, f32x2{-1.1511471f, -1.1511471f});
+    q = q * ag;
+    const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2 relu = {fmaxf(g[0], 0.0f), fmaxf(g[1], 0.0f)};
+    const f32x2 nh = ag * f32x2{-0.5f, -0.5f};
+    return a * __builtin_elementwise_fma(nh, e, relu);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
