@@ -28,7 +28,7 @@ namespace {
 #define STAMP(k)                                                                      \
     do {                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                            \
-        if (a.dbg && threadIdx.x == 0) a.dbg[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (a.dbg && threadIdx.x == 0) a.dbg[(long long)stamp_slot * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
 #else
@@ -46,7 +46,8 @@ struct ConvArgs {
     long long sx1, sw, so;
     int splitk;   // > 1: blockIdx.y selects a K slice, raw fp32 partial sums go to ws[slice][M][Cout]
     float* ws;
-    unsigned x1_bytes, x2_bytes, w_bytes;
+    unsigned x1_bytes, x2_bytes, w_bytes, res1_bytes, res2_bytes;
+    int pf_ahead;  // residual lines are pulled into L2 this many K-steps before the tile's K loop ends
 #ifdef CCNET_STAMP
     unsigned long long* dbg;  // diagnostic build only: per-block phase time stamps
 #endif
@@ -81,6 +82,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows per DMA pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef CCNET_STAMP
+    int stamp_slot = blockIdx.x;  // tile (virtual block) the stamps belong to
+#endif
     STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +109,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)x1, 0, a.x1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.res1, 0, a.res1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.res2, 0, a.res2_bytes, 0x00020000);
 
     const int lrow = tid / CPW, lchunk = tid % CPW;
     // 16-B chunk swizzle (applied on the DMA source and on the fragment read): conflict-free ds_read_b128
@@ -180,6 +186,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
     };
 
+    // The epilogue's residual loads are latency-bound (few 16-B loads in flight per lane: the accumulators own the
+    // registers), so shortly before the K loop ends every 128-B line of the tile's residual(s) is touched by a 4-B
+    // LDS-DMA into a junk LDS row: no registers, and the epilogue then reads L2 instead of HBM.
+    auto prefetch_res = [&](int pm0, int pn0) {
+        constexpr int LPR = BN / 64;  // 128-B lines per tile row
+        char* junk = smem + NS * STAGE;
+#pragma unroll
+        for (int t = 0; t < (BM * LPR + NT - 1) / NT; ++t) {
+            int tt = tid;
+            asm volatile("" : "+v"(tt));  // recomputed here: hoisted out of the K loop these indices cost live registers
+            const int idx = tt + t * NT, r = idx / LPR, ln = idx - r * LPR;
+            const int m = pm0 + r, c = pn0 + ln * 64;
+            const bool ok = idx < BM * LPR && m < a.M && c < a.Cout;
+            if (a.res1_bytes)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rres1, (__attribute__((address_space(3))) void*)junk, 4,
+                                                         ok ? (int)(((unsigned)m * a.ldres1 + c) * 2u) : (int)OOB, 0, 0, 0);
+            if (a.res2_bytes)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rres2, (__attribute__((address_space(3))) void*)junk, 4,
+                                                         ok ? (int)(((unsigned)m * a.ldres2 + c) * 2u) : (int)OOB, 0, 0, 0);
+        }
+    };
+
     const int swz = swz_of(l31);
     const int xrow_off = (wm * 32 * TJ + l31) * RB, wrow_off = (wn * 32 * TI + l31) * RB;
 
@@ -206,6 +234,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     int vb = blockIdx.x;
     start_tile(vb);
     for (;;) {  // one trip per tile (a single trip unless PERSIST)
+#ifdef CCNET_STAMP
+    stamp_slot = vb;
+#endif
     const int cm0 = m0, cn0 = n0;  // tile being computed; (m0, n0) move on to the next tile before the epilogue
     __builtin_amdgcn_sched_barrier(0);  // the first stages' DMAs are in flight before the accumulator-init loads go out
     // Accumulators start at bias[cout] (+ the image's time-embedding row): register (i, j, 4q + e) of a lane is cout
@@ -254,6 +285,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     int s = 0, sn = NS - 1;  // stage being read, stage being refilled
     for (int kt = 0; kt < KTl; ++kt) {
         const bool more = kt + NS - 1 < KTl;
+        if (!GEGLU && !SPLIT && kt == KTl - a.pf_ahead) prefetch_res(cm0, cn0);
         const char* xb = smem + s * STAGE;
         const char* wb = xb + BM * RB;
         if (more && cc_n == 0) set_tap(tap_n);
@@ -510,12 +542,13 @@ unsigned long long* g_dbg = nullptr;
 int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, bit1 = w descriptor empty
 
 constexpr int kNumCUs = 256;
-int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
+int g_persist = 1;
+int g_prefetch = 3;  // tuning: K-steps before the end of a tile's K loop at which residual lines are prefetched (0 = off)  // tuning: 0 = persistent configurations launch one block per tile
 
 template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false, bool PERSIST = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
-    constexpr int LDS = NS * (BM + BN) * BK * 2;
+    constexpr int LDS = NS * (BM + BN) * BK * 2 + 256;  // stages + the junk row of the residual prefetch
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST>,
@@ -552,14 +585,14 @@ const TileCfg kCfgs[] = {
     {128, 128, launch<2, 2, 2, 2, false>, launch<2, 2, 2, 2, true>, nullptr},   // 0: 4 waves, two blocks per CU
     {128, 64, launch<2, 1, 2, 2, false>, launch<2, 1, 2, 2, true>, nullptr},    // 1: 2 waves
     {64, 64, launch<1, 1, 2, 2, false>, launch<1, 1, 2, 2, true>, nullptr},     // 2: 1 wave, tiny problems
-    {128, 320, launch<2, 2, 2, 5, false>, nullptr, nullptr},                     // 3: 4 waves, Cout = 320 without waste
+    {128, 320, launch<2, 2, 2, 5, false>, nullptr, launch<2, 2, 2, 5, false, 2, 64, true>},  // 3: 4 waves, Cout = 320 without waste
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},  // 4-6
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},  // 7-9
     {256, 256, launch<4, 2, 2, 4, false>, nullptr, nullptr},                     // 10: 8 waves, 2 x 64-deep stages
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 11-12
     {128, 128, launch<2, 2, 2, 2, false, 3>, nullptr, nullptr},                  // 13: 4 waves, 3 stages
     {0, 0, nullptr, nullptr, nullptr},                                           // 14
-    {256, 128, launch<4, 2, 2, 2, false, 3>, nullptr, nullptr},                  // 15: 8 waves, 3 stages
+    {256, 128, launch<4, 2, 2, 2, false, 3>, nullptr, launch<4, 2, 2, 2, false, 3, 64, true>},  // 15: 8 waves, 3 stages
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},  // 16-18
     {128, 128, launch<4, 2, 1, 2, false, 3>, nullptr, launch<4, 2, 1, 2, false, 3, 64, true>},  // 19: 8 waves, 3 stages
     {256, 256, launch<4, 2, 2, 4, false, 4, 32, false, true>, launch<4, 2, 2, 4, true, 4, 32, false, true>, nullptr},    // 20: 8 waves, 4 x 32-deep
@@ -567,7 +600,7 @@ const TileCfg kCfgs[] = {
     {256, 320, launch<4, 2, 2, 5, false, 2, 64, false, true>, nullptr, launch<4, 2, 2, 5, false, 2, 64, true>},  // 23: 8 waves
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 24-25
     {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>, nullptr},    // 26: 4 waves, 72 KB
-    {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr, nullptr},              // 27: 4 waves, 57 KB
+    {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr, launch<2, 2, 2, 5, false, 2, 32, true>},  // 27: 4 waves, 57 KB
     {128, 128, launch<2, 2, 2, 2, false, 3, 32>, nullptr, nullptr},              // 28: 48 KB: three blocks per CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -606,6 +639,7 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 2) { g_order = value; return CCNET_OK; }
     if (key == 3) { g_force_splitk = value; return CCNET_OK; }
     if (key == 4) { g_persist = value; return CCNET_OK; }
+    if (key == 5) { g_prefetch = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
@@ -666,15 +700,24 @@ namespace {
 int plan_splitk(const ccnet_conv_params* p, int M, int KT, int batch, int* cfg) {
     if (p->act == 2 || batch > 1) return 1;
     auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((p->Cout + bn - 1) / bn); };
-    int S = 1;
+    // measured (tools/sweep_splitk.sh, cold weights): 16x16 level (M 8192, 128 tiles of 256x320): S = 2 on the 256x320 tile;
+    // 8x8 level (M 2048): 80 tiles of 256x128 x S = 3 beats 32 tiles of 256x320 x S = 8 by 15-30 % (a third of the fp32
+    // partial-sum traffic, 240 blocks)
+    int S = 1, scfg = 23;
+    const long long t23 = (p->Cout % 320) == 0 ? tiles(256, 320) : 0, t15 = (p->Cout % 128) == 0 ? tiles(256, 128) : 0;
     if (g_force_splitk > 0) {
         S = g_force_splitk;
-    } else if ((p->Cout % 320) == 0 && tiles(256, 320) < 200) {
-        S = (int)(256 / tiles(256, 320));
-        if (S > 8) S = 8;
+    } else if (t23 >= 100 && t23 < 200) {
+        S = (int)(256 / t23);
+    } else if (t15 > 0 && t15 < 128) {
+        S = (int)(256 / t15);
+        scfg = 15;
+    } else if (t23 > 0 && t23 < 100) {
+        S = (int)(256 / t23);
     }
-    while (S > 1 && KT / S < 12) --S;  // every slice keeps a real K loop
-    if (S > 1 && (*cfg < 0 || !kCfgs[*cfg].fn_split)) *cfg = 23;  // the tile the split is planned for
+    if (S > 8) S = 8;
+    while (S > 1 && KT / S < 13) --S;  // every slice keeps a real K loop (K = 1280 at the 8x8 level loses with S = 2)
+    if (S > 1 && (g_force_cfg < 0 || *cfg < 0 || !kCfgs[*cfg].fn_split)) *cfg = scfg;
     return S;
 }
 }  // namespace
@@ -734,6 +777,15 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     a.x1_bytes = (unsigned)xb1; a.x2_bytes = (unsigned)xb2; a.w_bytes = (unsigned)wb;
     if (g_dbg_zero & 1) { a.x1_bytes = 0; a.x2_bytes = 0; }
     if (g_dbg_zero & 2) a.w_bytes = 0;
+    {
+        const long long rb1 = p->res1 ? ((long long)a.M - 1) * p->ldres1 * 2 + (long long)p->Cout * 2 : 0;
+        const long long rb2 = p->res2 ? ((long long)a.M - 1) * p->ldres2 * 2 + (long long)p->Cout * 2 : 0;
+        const bool pf = g_prefetch > 0 && batch == 1 && rb1 < 0x7fffffffLL && rb2 < 0x7fffffffLL;
+        a.res1_bytes = pf ? (unsigned)rb1 : 0;
+        a.res2_bytes = pf ? (unsigned)rb2 : 0;
+        a.pf_ahead = a.KT < g_prefetch ? a.KT : g_prefetch;  // (KTl >= this for every split: slices keep >= 12 steps)
+        if (!pf || (!p->res1 && !p->res2)) a.pf_ahead = -1;  // never matches a K-step
+    }
 #ifdef CCNET_STAMP
     a.dbg = g_dbg;
 #endif

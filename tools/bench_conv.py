@@ -36,6 +36,14 @@ SHAPES = [
     ("L0 o-proj 320->320 +res @64", 32, 64, 320, 0, 320, 1, 1, 1, True),
     ("L1 o-proj 640->640 +res @32", 32, 32, 640, 0, 640, 1, 1, 1, True),
     ("L2 o-proj 1280->1280 +res @16", 32, 16, 1280, 0, 1280, 1, 1, 1, True),
+    ("mid ff2 5120->1280 +res @8", 32, 8, 5120, 0, 1280, 1, 1, 1, True),
+    ("U0 skip 1x1 2560->1280 @8", 32, 8, 2560, 0, 1280, 1, 1, 1),
+    ("L3 conv3x3 1280->1280 +res @8", 32, 8, 1280, 0, 1280, 3, 1, 1, True),
+    ("L0 conv3x3 320->320 +res @64", 32, 64, 320, 0, 320, 3, 1, 1, True),
+    ("L1 conv3x3 640->640 +res @32", 32, 32, 640, 0, 640, 3, 1, 1, True),
+    ("L0 ff2 1280->320 +res @64", 32, 64, 1280, 0, 320, 1, 1, 1, True),
+    ("L1 ff2 2560->640 +res @32", 32, 32, 2560, 0, 640, 1, 1, 1, True),
+    ("L2 ff2 5120->1280 +res @16", 32, 16, 5120, 0, 1280, 1, 1, 1, True),
     ("mid 1x1 1280->1280 @8", 32, 8, 1280, 0, 1280, 1, 1, 1),
     ("L0 ff1+GEGLU 320->2560 @64", 32, 64, 320, 0, 2560, 1, 1, 1, False, 2),
     ("L1 ff1+GEGLU 640->5120 @32", 32, 32, 640, 0, 5120, 1, 1, 1, False, 2),
@@ -54,10 +62,12 @@ def main():
     ap.add_argument("--splitk", type=int, default=0, help="force the split-K factor (0 = heuristic)")
     ap.add_argument("--order", type=int, default=-1, help="force tile order: 0 N-fastest, 1 M-fastest")
     ap.add_argument("--persist", type=str, default="1", help="comma list: 1 persistent launches, 0 one block per tile")
+    ap.add_argument("--prefetch", type=str, default="3", help="comma list: residual prefetch distance in K-steps (0 off)")
     ap.add_argument("--cold", action="store_true", help="rotate over 12 weight copies so weights come from HBM")
     args = ap.parse_args()
     from ccnet_amd import lib as _lib
-    cfgs = [(int(c), int(pp)) for c in args.cfgs.split(",") for pp in args.persist.split(",")]
+    cfgs = [(int(c), int(pp), int(pf)) for c in args.cfgs.split(",") for pp in args.persist.split(",")
+            for pf in args.prefetch.split(",")]
     if args.dbg_zero:
         from ccnet_amd import lib
         lib.load().ccnet_set_option(1, args.dbg_zero)
@@ -85,12 +95,14 @@ def main():
         rs = []
         _lib.load().ccnet_set_option(0, -1)
         _lib.load().ccnet_set_option(4, 0)
+        _lib.load().ccnet_set_option(5, 0)
         ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act).t.clone()
-        for cfg, pers in cfgs:
+        for cfg, pers, pf in cfgs:
             _lib.load().ccnet_set_option(0, cfg)
             _lib.load().ccnet_set_option(4, pers)
+            _lib.load().ccnet_set_option(5, pf)
             try:
-                for _ in range(2):
+                for _ in range(6):
                     o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act)
             except Exception as e:  # report and keep sweeping
                 print(f"cfg {cfg} failed: {e}", flush=True)
@@ -113,8 +125,8 @@ def main():
         best = max(range(len(cfgs)), key=lambda i: rs[i][0])
         tot_f += flops
         tot_t += rs[best][1]
-        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c[0]}{'p' if c[1] else ''}:{r[0]:6.0f}" for c, r in zip(cfgs, rs))
-              + f"  best c{cfgs[best][0]}{'p' if cfgs[best][1] else ''} {rs[best][1] * 1e3:7.1f} us", flush=True)
+        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c[0]}{'p' if c[1] else ''}f{c[2]}:{r[0]:6.0f}" for c, r in zip(cfgs, rs))
+              + f"  best c{cfgs[best][0]}{'p' if cfgs[best][1] else ''}f{cfgs[best][2]} {rs[best][1] * 1e3:7.1f} us", flush=True)
     if tot_t:
         print(f"{'TOTAL of best (equal weight)':34s} {tot_f / tot_t / 1e9:7.1f} TF/s")
 

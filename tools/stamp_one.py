@@ -46,3 +46,17 @@ print(f"blocks {len(d)}  kernel span {(t[:, 4].max() - t[:, 0].min()):.0f} ticks
 for i, nm in enumerate(names):
     print(f"  {nm:16s} mean {ph[:, i].mean():9.0f}  p10 {np.percentile(ph[:, i], 10):9.0f}  p90 {np.percentile(ph[:, i], 90):9.0f}")
 print(f"  per-block total  mean {(t[:, 4] - t[:, 0]).mean():9.0f}")
+
+# persistent launches: stamps 2..4 exist per tile (slot = virtual block); look at lockstep between the CUs
+full = dbg.cpu().numpy().reshape(-1, 8)
+rows = np.nonzero(full[:, 4] != 0)[0]
+if len(rows) > len(d):
+    G = 256
+    t0 = full[rows, 2].min()
+    print(f"tiles stamped {len(rows)}; per round of {G} tiles: start-of-loop / end-of-loop / end-of-epilogue, ticks from t0")
+    for r in range(0, min(len(rows) // G, 8)):
+        sel = rows[(rows >= r * G) & (rows < (r + 1) * G)]
+        a2, a3, a4 = (full[sel, k].astype(np.float64) - t0 for k in (2, 3, 4))
+        print(f"  round {r}: loop start {a2.mean():8.0f} +- {a2.std():6.0f}   loop {np.mean(a3 - a2):7.0f}   "
+              f"epilogue {np.mean(a4 - a3):7.0f} (p10 {np.percentile(a4 - a3, 10):6.0f} p90 {np.percentile(a4 - a3, 90):6.0f})   "
+              f"epilogue-end spread (std) {a4.std():6.0f}")
