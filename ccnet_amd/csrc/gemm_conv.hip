@@ -46,8 +46,7 @@ struct ConvArgs {
     long long sx1, sw, so;
     int splitk;   // > 1: blockIdx.y selects a K slice, raw fp32 partial sums go to ws[slice][M][Cout]
     float* ws;
-    unsigned x1_bytes, x2_bytes, w_bytes, res1_bytes, res2_bytes;
-    int pf_ahead;  // residual lines are pulled into L2 this many K-steps before the tile's K loop ends
+    unsigned x1_bytes, x2_bytes, w_bytes;
 #ifdef CCNET_STAMP
     unsigned long long* dbg;  // diagnostic build only: per-block phase time stamps
 #endif
@@ -109,8 +108,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)x1, 0, a.x1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, a.x2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, a.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rres1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.res1, 0, a.res1_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rres2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.res2, 0, a.res2_bytes, 0x00020000);
 
     const int lrow = tid / CPW, lchunk = tid % CPW;
     // 16-B chunk swizzle (applied on the DMA source and on the fragment read): conflict-free ds_read_b128
@@ -184,28 +181,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     auto advance = [&]() {
         ++kt_n;
         if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
-    };
-
-    // The epilogue's residual loads are latency-bound (few 16-B loads in flight per lane: the accumulators own the
-    // registers), so shortly before the K loop ends every 128-B line of the tile's residual(s) is touched by a 4-B
-    // LDS-DMA into a junk LDS row: no registers, and the epilogue then reads L2 instead of HBM.
-    auto prefetch_res = [&](int pm0, int pn0) {
-        constexpr int LPR = BN / 64;  // 128-B lines per tile row
-        char* junk = smem + NS * STAGE;
-#pragma unroll
-        for (int t = 0; t < (BM * LPR + NT - 1) / NT; ++t) {
-            int tt = tid;
-            asm volatile("" : "+v"(tt));  // recomputed here: hoisted out of the K loop these indices cost live registers
-            const int idx = tt + t * NT, r = idx / LPR, ln = idx - r * LPR;
-            const int m = pm0 + r, c = pn0 + ln * 64;
-            const bool ok = idx < BM * LPR && m < a.M && c < a.Cout;
-            if (a.res1_bytes)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rres1, (__attribute__((address_space(3))) void*)junk, 4,
-                                                         ok ? (int)(((unsigned)m * a.ldres1 + c) * 2u) : (int)OOB, 0, 0, 0);
-            if (a.res2_bytes)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rres2, (__attribute__((address_space(3))) void*)junk, 4,
-                                                         ok ? (int)(((unsigned)m * a.ldres2 + c) * 2u) : (int)OOB, 0, 0, 0);
-        }
     };
 
     const int swz = swz_of(l31);
@@ -285,7 +260,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     int s = 0, sn = NS - 1;  // stage being read, stage being refilled
     for (int kt = 0; kt < KTl; ++kt) {
         const bool more = kt + NS - 1 < KTl;
-        if (!GEGLU && !SPLIT && kt == KTl - a.pf_ahead) prefetch_res(cm0, cn0);
         const char* xb = smem + s * STAGE;
         const char* wb = xb + BM * RB;
         if (more && cc_n == 0) set_tap(tap_n);
@@ -542,13 +516,12 @@ unsigned long long* g_dbg = nullptr;
 int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, bit1 = w descriptor empty
 
 constexpr int kNumCUs = 256;
-int g_persist = 1;
-int g_prefetch = 3;  // tuning: K-steps before the end of a tile's K loop at which residual lines are prefetched (0 = off)  // tuning: 0 = persistent configurations launch one block per tile
+int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
 template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false, bool PERSIST = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
-    constexpr int LDS = NS * (BM + BN) * BK * 2 + 256;  // stages + the junk row of the residual prefetch
+    constexpr int LDS = NS * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST>,
@@ -639,7 +612,6 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 2) { g_order = value; return CCNET_OK; }
     if (key == 3) { g_force_splitk = value; return CCNET_OK; }
     if (key == 4) { g_persist = value; return CCNET_OK; }
-    if (key == 5) { g_prefetch = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
@@ -766,10 +738,7 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     a.M = p->N * p->Hout * p->Wout; a.HWout = p->Hout * p->Wout;
     a.CT1 = p->C1 / 64; a.CT = (p->C1 + p->C2) / 64; a.KT = p->R * p->R * a.CT;
     a.sx1 = p->sx1; a.sw = p->sw; a.so = p->so;
-    {
-        const long long wbytes = (long long)p->Cout * a.KT * 128, xbytes = (long long)p->N * p->Hin * p->Win * a.CT * 128;
-        a.mfast = g_order >= 0 ? g_order : (wbytes > xbytes);
-    }
+    a.mfast = g_order > 0;  // M-fastest tile order only on request: measured no better than N-fastest on any G1 layer
     const long long xb1 = ((long long)p->N * p->Hin * p->Win - 1) * p->ldx1 * 2 + (long long)p->C1 * 2;
     const long long xb2 = p->C2 ? ((long long)p->N * p->Hin * p->Win - 1) * p->ldx2 * 2 + (long long)p->C2 * 2 : 0;
     const long long wb = ((long long)p->Cout - 1) * p->ldw * 2 + (long long)a.KT * 128;
@@ -777,15 +746,6 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     a.x1_bytes = (unsigned)xb1; a.x2_bytes = (unsigned)xb2; a.w_bytes = (unsigned)wb;
     if (g_dbg_zero & 1) { a.x1_bytes = 0; a.x2_bytes = 0; }
     if (g_dbg_zero & 2) a.w_bytes = 0;
-    {
-        const long long rb1 = p->res1 ? ((long long)a.M - 1) * p->ldres1 * 2 + (long long)p->Cout * 2 : 0;
-        const long long rb2 = p->res2 ? ((long long)a.M - 1) * p->ldres2 * 2 + (long long)p->Cout * 2 : 0;
-        const bool pf = g_prefetch > 0 && batch == 1 && rb1 < 0x7fffffffLL && rb2 < 0x7fffffffLL;
-        a.res1_bytes = pf ? (unsigned)rb1 : 0;
-        a.res2_bytes = pf ? (unsigned)rb2 : 0;
-        a.pf_ahead = a.KT < g_prefetch ? a.KT : g_prefetch;  // (KTl >= this for every split: slices keep >= 12 steps)
-        if (!pf || (!p->res1 && !p->res2)) a.pf_ahead = -1;  // never matches a K-step
-    }
 #ifdef CCNET_STAMP
     a.dbg = g_dbg;
 #endif

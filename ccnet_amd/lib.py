@@ -90,6 +90,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
             fn.restype = C.c_int
+    # tuning knobs for A/B timing (tools/, bench.py): CCNET_HIP_OPTIONS="key=value,key=value" -> ccnet_set_option
+    for kv in filter(None, os.environ.get("CCNET_HIP_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        if lib.ccnet_set_option(int(k), int(v)) != 0:
+            raise CcnetError(f"CCNET_HIP_OPTIONS: unknown option {kv!r}")
     _lib = lib
     return lib
 

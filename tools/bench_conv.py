@@ -62,12 +62,10 @@ def main():
     ap.add_argument("--splitk", type=int, default=0, help="force the split-K factor (0 = heuristic)")
     ap.add_argument("--order", type=int, default=-1, help="force tile order: 0 N-fastest, 1 M-fastest")
     ap.add_argument("--persist", type=str, default="1", help="comma list: 1 persistent launches, 0 one block per tile")
-    ap.add_argument("--prefetch", type=str, default="3", help="comma list: residual prefetch distance in K-steps (0 off)")
     ap.add_argument("--cold", action="store_true", help="rotate over 12 weight copies so weights come from HBM")
     args = ap.parse_args()
     from ccnet_amd import lib as _lib
-    cfgs = [(int(c), int(pp), int(pf)) for c in args.cfgs.split(",") for pp in args.persist.split(",")
-            for pf in args.prefetch.split(",")]
+    cfgs = [(int(c), int(pp)) for c in args.cfgs.split(",") for pp in args.persist.split(",")]
     if args.dbg_zero:
         from ccnet_amd import lib
         lib.load().ccnet_set_option(1, args.dbg_zero)
@@ -95,12 +93,10 @@ def main():
         rs = []
         _lib.load().ccnet_set_option(0, -1)
         _lib.load().ccnet_set_option(4, 0)
-        _lib.load().ccnet_set_option(5, 0)
         ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act).t.clone()
-        for cfg, pers, pf in cfgs:
+        for cfg, pers in cfgs:
             _lib.load().ccnet_set_option(0, cfg)
             _lib.load().ccnet_set_option(4, pers)
-            _lib.load().ccnet_set_option(5, pf)
             try:
                 for _ in range(6):
                     o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act)
@@ -125,8 +121,8 @@ def main():
         best = max(range(len(cfgs)), key=lambda i: rs[i][0])
         tot_f += flops
         tot_t += rs[best][1]
-        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c[0]}{'p' if c[1] else ''}f{c[2]}:{r[0]:6.0f}" for c, r in zip(cfgs, rs))
-              + f"  best c{cfgs[best][0]}{'p' if cfgs[best][1] else ''}f{cfgs[best][2]} {rs[best][1] * 1e3:7.1f} us", flush=True)
+        print(f"{name:32s} M={o.rows:7d} N={Cout:5d} K={K:5d} " + " ".join(f"c{c[0]}{'p' if c[1] else ''}:{r[0]:6.0f}" for c, r in zip(cfgs, rs))
+              + f"  best c{cfgs[best][0]}{'p' if cfgs[best][1] else ''} {rs[best][1] * 1e3:7.1f} us", flush=True)
     if tot_t:
         print(f"{'TOTAL of best (equal weight)':34s} {tot_f / tot_t / 1e9:7.1f} TF/s")
 
