@@ -578,7 +578,7 @@ const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-int pick_cfg(int M, int Cout, int K, int batch, bool geglu) {
+int pick_cfg(int M, int Cout, int K, int batch, bool geglu, bool has_res) {
     if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (geglu ? kCfgs[g_force_cfg].fn_geglu : kCfgs[g_force_cfg].fn))
         return g_force_cfg;
     auto blocks = [&](int c) {
@@ -592,7 +592,13 @@ int pick_cfg(int M, int Cout, int K, int batch, bool geglu) {
     if (geglu) {
         if ((Cout % 256) == 0 && tiles(256, 256) >= 200) return 20;
     } else {
+        // K = 320 with a residual is HBM-bound and epilogue-heavy: three small blocks per CU overlap one block's
+        // residual loads and stores with the others' K loops (+9 % over the 256x320 tile)
+        if (has_res && K <= 320 && tiles(128, 128) >= 1024) return 28;
         if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
+        // 16x16 level, K too short to split: 128x320 fills every CU (256 tiles, two blocks per CU) where 256x256 leaves
+        // 160 tiles (+20 %)
+        if ((Cout % 320) == 0 && tiles(256, 320) < 200 && tiles(128, 320) >= 200) return 3;
         if ((Cout % 256) == 0 && tiles(256, 256) >= 150) return Cout == 256 ? 10 : 20;
         if ((Cout % 128) == 0 && tiles(256, 128) >= 200) return 15;
         if (M <= 4096 && tiles(128, 128) >= 100) return 19;
@@ -766,7 +772,7 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
         (void)hipEventRecord(rec->e0, st);
     }
     const bool geglu = p->act == 2;
-    int cfg_i = pick_cfg(a.M, p->Cout, a.KT * 64, batch, geglu);
+    int cfg_i = pick_cfg(a.M, p->Cout, a.KT * 64, batch, geglu, p->res1 != nullptr);
     a.splitk = plan_splitk(p, a.M, a.KT, batch, &cfg_i);
     if (a.splitk > 1) {
         if (!p->workspace || p->workspace_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return CCNET_EWS;

@@ -36,6 +36,9 @@ SHAPES = [
     ("L0 o-proj 320->320 +res @64", 32, 64, 320, 0, 320, 1, 1, 1, True),
     ("L1 o-proj 640->640 +res @32", 32, 32, 640, 0, 640, 1, 1, 1, True),
     ("L2 o-proj 1280->1280 +res @16", 32, 16, 1280, 0, 1280, 1, 1, 1, True),
+    ("L2 qkv 1280->3840 @16", 32, 16, 1280, 0, 3840, 1, 1, 1),
+    ("L2 proj 1x1 1280->1280 @16", 32, 16, 1280, 0, 1280, 1, 1, 1),
+    ("L1 qkv 640->1920 @32", 32, 32, 640, 0, 1920, 1, 1, 1),
     ("mid ff2 5120->1280 +res @8", 32, 8, 5120, 0, 1280, 1, 1, 1, True),
     ("U0 skip 1x1 2560->1280 @8", 32, 8, 2560, 0, 1280, 1, 1, 1),
     ("L3 conv3x3 1280->1280 +res @8", 32, 8, 1280, 0, 1280, 3, 1, 1, True),
