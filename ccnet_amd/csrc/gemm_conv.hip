@@ -592,9 +592,6 @@ int pick_cfg(int M, int Cout, int K, int batch, bool geglu, bool has_res) {
     if (geglu) {
         if ((Cout % 256) == 0 && tiles(256, 256) >= 200) return 20;
     } else {
-        // K = 320 with a residual is HBM-bound and epilogue-heavy: three small blocks per CU overlap one block's
-        // residual loads and stores with the others' K loops (+9 % over the 256x320 tile)
-        if (has_res && K <= 320 && tiles(128, 128) >= 1024) return 28;
         if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
         // 16x16 level, K too short to split: 128x320 fills every CU (256 tiles, two blocks per CU) where 256x256 leaves
         // 160 tiles (+20 %)
