@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every launch from the host (rocprofv3 --pmc passes: counter collection crashes on graph replay)")
     ap.add_argument("--shapes", type=str, default="", help="write the per-shape conv timing table to this file")
     args = ap.parse_args()
 
@@ -144,7 +146,8 @@ def main():
     cn, un, vae = build_models(dev, acq)
     sch = DDIMScheduler(clip_sample=False, **SCHED)
     sch.set_timesteps(args.ddim_steps)
-    sampler = Sampler(cn, un, sch, vae, guidance_scale=7.0, conditioning_scale=1.0, scale_factor=0.1)
+    sampler = Sampler(cn, un, sch, vae, guidance_scale=7.0, conditioning_scale=1.0, scale_factor=0.1,
+                      use_graph=not args.no_graph)
 
     B = args.batch
     nb = args.warmup + args.steps
