@@ -261,41 +261,79 @@ int launch_conv_in_small(const float* x, int Nsrc, int N, int H, int W, const fl
     return CCNET_OK;
 }
 
-// conv_out_small: NHWC bf16 -> fp32 NCHW, Cout <= 8, 3x3 stride 1 pad 1; one wave per output pixel.
+// conv_out_small: NHWC bf16 -> fp32 NCHW, Cout <= 8, 3x3 stride 1 pad 1 (UNet / AEKL output convolutions).
+// HBM-bound (the input is read once, the output is tiny).  A group of G lanes (G = Cin/8 rounded up to a power of two, one
+// 16-B channel chunk per lane) owns a strip of 8 output pixels of one row; per input row the lane loads its chunk of the
+// 10 input pixels the strip touches once and reuses it for the three horizontal taps, the weight chunk of a (tap, cout) is
+// loaded once per strip, and products accumulate in fp32 (bf16 -> fp32 is a shift).  The G partial sums of each (pixel, cout) are combined by a butterfly at the end.
+template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_small_kernel(const __bf16* x, int ldx, int N, int H, int W, int Cin,
-                                                             const __bf16* w, const float* bias, int Cout,
-                                                             float* out) {
+                                                             const __bf16* w, const float* bias, float* out, int G) {
+    constexpr int P = 8;
     const int lane = threadIdx.x & 63;
-    const long long npix = (long long)N * H * W;
-    const int cols = Cin / 8;
-    for (long long pixel = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pixel < npix; pixel += (long long)gridDim.x * 4) {
-        const int ox = (int)(pixel % W), oy = (int)((pixel / W) % H), n = (int)(pixel / ((long long)W * H));
-        float acc[8];
+    const int spw = 64 / G;  // strips per wave
+    const int sub = lane / G, col = lane - sub * G;
+    const bool active = col * 8 < Cin;
+    const int spr = (W + P - 1) / P;  // strips per row
+    const long long nstrips = (long long)N * H * spr;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long sw = wave0; sw * spw < nstrips; sw += (long long)gridDim.x * 4) {
+        const long long strip = sw * spw + sub;
+        const bool sok = strip < nstrips && active;
+        const long long st = strip < nstrips ? strip : 0;
+        const int sx = (int)(st % spr), oy = (int)((st / spr) % H), n = (int)(st / ((long long)spr * H));
+        const int ox0 = sx * P;
+        float acc[P][COUT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int tap = 0; tap < 9; ++tap) {
-            const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
-            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;  // wave-uniform
-            const __bf16* xp = x + (((long long)n * H + iy) * W + ix) * ldx;
-            for (int col = lane; col < cols; col += 64) {
-                float xv[8];
-                unpack8(*(const u32x4*)(xp + col * 8), xv);
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-                for (int co = 0; co < 8; ++co) {
-                    if (co < Cout) {
-                        float wv[8];
-                        unpack8(*(const u32x4*)(w + ((long long)co * 9 + tap) * Cin + col * 8), wv);
+            for (int co = 0; co < COUT; ++co) acc[p][co] = 0.f;
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy + dy - 1;
+            const bool rok = sok && (unsigned)iy < (unsigned)H;
+            const __bf16* xrow = x + (((long long)n * H + (rok ? iy : 0)) * W) * ldx + col * 8;
+            u32x4 xv[P + 2];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[co] += xv[e] * wv[e];
-                    }
-                }
+            for (int k = 0; k < P + 2; ++k) {
+                const int ix = ox0 - 1 + k;
+                const bool ok = rok && (unsigned)ix < (unsigned)W;
+                xv[k] = ok ? *(const u32x4*)(xrow + (long long)ix * ldx) : u32x4{0u, 0u, 0u, 0u};
             }
-        }
 #pragma unroll
-        for (int co = 0; co < 8; ++co) {
-            if (co < Cout) {
-                const float s = wave_sum(acc[co]);
-                if (lane == 0) out[(((long long)n * Cout + co) * H + oy) * W + ox] = s + (bias ? bias[co] : 0.f);
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const u32x4 wv = active ? *(const u32x4*)(w + ((long long)co * 9 + dy * 3 + dx) * Cin + col * 8)
+                                            : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // (v_dot2c_f32_bf16 through __builtin_amdgcn_fdot2_f32_bf16 returned wrong sums here; plain fma)
+                            const unsigned xa = xv[p + dx][e], wa = wv[e];
+                            acc[p][co] = fmaf(__uint_as_float(xa << 16), __uint_as_float(wa << 16), acc[p][co]);
+                            acc[p][co] = fmaf(__uint_as_float(xa & 0xffff0000u), __uint_as_float(wa & 0xffff0000u), acc[p][co]);
+                        }
+                }
+        }
+        // butterfly over the G lanes of the strip
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float v = acc[p][co];
+                for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                acc[p][co] = v;
+            }
+        if (col == 0 && strip < nstrips) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float b = bias ? bias[co] : 0.f;
+                float* o = out + (((long long)n * COUT + co) * H + oy) * W + ox0;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    if (ox0 + p < W) o[p] = acc[p][co] + b;
             }
         }
     }
@@ -469,8 +507,25 @@ extern "C" int ccnet_conv_out_small(const void* x, int ldx, int N, int H, int W,
                                     const float* bias, int Cout, float* out, void* stream) {
     if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8) || (ldx % 8) || Cout <= 0 || Cout > 8)
         return CCNET_EINVAL;
-    hipLaunchKernelGGL(conv_out_small_kernel, dim3(grid_for((long long)N * H * W, 4)), dim3(256), 0,
-                       (hipStream_t)stream, (const __bf16*)x, ldx, N, H, W, Cin, (const __bf16*)w, bias, Cout, out);
+    if (Cin > 512) return CCNET_EUNSUP;  // one 16-B channel chunk per lane
+    int G = 1;
+    while (G * 8 < Cin) G <<= 1;
+    const long long waves = ((long long)N * H * ((W + 7) / 8) + (64 / G) - 1) / (64 / G);
+    const dim3 grid(grid_for(waves, 4));
+    hipStream_t st = (hipStream_t)stream;
+#define COS_LAUNCH(C) \
+    hipLaunchKernelGGL(conv_out_small_kernel<C>, grid, dim3(256), 0, st, (const __bf16*)x, ldx, N, H, W, Cin, (const __bf16*)w, bias, out, G)
+    switch (Cout) {
+        case 1: COS_LAUNCH(1); break;
+        case 2: COS_LAUNCH(2); break;
+        case 3: COS_LAUNCH(3); break;
+        case 4: COS_LAUNCH(4); break;
+        case 5: COS_LAUNCH(5); break;
+        case 6: COS_LAUNCH(6); break;
+        case 7: COS_LAUNCH(7); break;
+        default: COS_LAUNCH(8); break;
+    }
+#undef COS_LAUNCH
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }
