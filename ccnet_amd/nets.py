@@ -132,6 +132,9 @@ class _Trunk(nn.Module):
         self.num_head_channels_ = _tuple(num_head_channels, n)
         self.attention_levels_ = tuple(bool(a) for a in attention_levels)
         self.norm_num_groups, self.norm_eps = norm_num_groups, norm_eps
+        # monai-generative hands the network's norm_eps to SpatialTransformer.norm; diffusers' Transformer2DModel fixes
+        # its GroupNorm at 1e-6 (ccnet_amd.diffusers_dialect overrides this attribute)
+        self.transformer_norm_eps = norm_eps
         self.with_conditioning = with_conditioning
         self.cross_attention_dim = cross_attention_dim
         c0 = num_channels[0]
@@ -363,7 +366,7 @@ class _Trunk(nn.Module):
             if hc == 64:  # flash kernel (SD-2.1 geometry)
                 return ops.attention_d64(q, k, v, B, heads, T, Skv, scale)
             return ops.attention_generic(q, k, v, B, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
-        h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.norm_eps, False)
+        h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.transformer_norm_eps, False)
         t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
         n1 = ops.layernorm(t, inner, *p["ln1"])
         qkv = ops.linear(n1, p["qkv1"], None, 3 * inner, inner)
@@ -659,6 +662,12 @@ def adjust_class_embedding(model: nn.Module) -> None:
     """util.py:1094-1132: continuous acquisition-time conditioning -- Linear(1, ted) -> SiLU -> Linear(ted, ted)."""
     name = str(model.__class__.__name__)
     if not (("DiffusionModelUNet" in name or "ControlNet" in name) and hasattr(model, "block_out_channels")):
+        if hasattr(model, "config") or "ControlNetModel" in name:  # diffusers naming convention (util.py:1113-1123)
+            model.config.num_class_embeds = int(99999)
+            ted = model.config.time_embedding_dim or model.config.block_out_channels[0] * 4
+            dev = next(model.parameters()).device
+            model.class_embedding = nn.Sequential(nn.Linear(1, ted), nn.SiLU(), nn.Linear(ted, ted)).to(dev)
+            return
         raise ValueError(f"{name} has neither key ('x' AND 'block_out_channels') nor key 'config'. "
                          f"Current diffusion model keys: {model.__dict__.keys()}")
     model.num_class_embeds = int(99999)

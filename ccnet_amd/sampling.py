@@ -33,8 +33,9 @@ def sample_from_controlnet(controlnet, noisy_e, controlnet_cond, timesteps, prom
     if hasattr(controlnet, "x") or "ControlNetModel" not in str(controlnet.__class__.__name__):
         return controlnet(x=noisy_e, timesteps=timesteps, context=prompt_embeds, controlnet_cond=controlnet_cond,
                           conditioning_scale=conditioning_scale, class_labels=class_labels)
-    raise NotImplementedError("diffusers ControlNetModel kwargs dialect: only the monai-generative surface is "
-                              "implemented (SURVEY.md section 8(f) item 1)")
+    return controlnet(sample=noisy_e, timestep=timesteps, encoder_hidden_states=prompt_embeds,
+                      controlnet_cond=controlnet_cond, conditioning_scale=conditioning_scale,
+                      class_labels=class_labels, return_dict=False)  # diffusers dialect, util.py:953-961
 
 
 def sample_from_ldm(model, noisy_e, timesteps, prompt_embeds, down_block_res_samples=None, mid_block_res_sample=None,
@@ -47,8 +48,13 @@ def sample_from_ldm(model, noisy_e, timesteps, prompt_embeds, down_block_res_sam
         return model(x=noisy_e, timesteps=timesteps, context=prompt_embeds, class_labels=class_labels,
                      down_block_additional_residuals=down_block_res_samples,
                      mid_block_additional_residual=mid_block_res_sample)
-    raise NotImplementedError("diffusers UNet2DConditionModel kwargs dialect: only the monai-generative surface is "
-                              "implemented (SURVEY.md section 8(f) item 1)")
+    # diffusers dialect, util.py:1071-1091
+    if down_block_res_samples is None or mid_block_res_sample is None:
+        return model(sample=noisy_e, timestep=timesteps, encoder_hidden_states=prompt_embeds,
+                     class_labels=class_labels).sample
+    return model(sample=noisy_e, timestep=timesteps, encoder_hidden_states=prompt_embeds, class_labels=class_labels,
+                 down_block_additional_residuals=down_block_res_samples,
+                 mid_block_additional_residual=mid_block_res_sample).sample
 
 
 def to_uint8(sample: torch.Tensor) -> torch.Tensor:
@@ -62,6 +68,11 @@ class Sampler:
     def __init__(self, controlnet, diffusion, scheduler, stage1=None, guidance_scale: Optional[float] = None,
                  conditioning_scale: float = 1.0, scale_factor: float = 0.01, cfg: bool = True,
                  use_graph: bool = True):
+        # diffusers-dialect wrappers (ccnet_amd.diffusers_dialect) hold the lowered network as `_net`
+        for m in (controlnet, diffusion):
+            if hasattr(m, "_sync"):
+                m._sync()
+        controlnet, diffusion = getattr(controlnet, "_net", controlnet), getattr(diffusion, "_net", diffusion)
         self.controlnet, self.diffusion, self.scheduler, self.stage1 = controlnet, diffusion, scheduler, stage1
         self.guidance_scale = guidance_scale
         self.conditioning_scale = conditioning_scale

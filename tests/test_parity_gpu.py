@@ -221,3 +221,57 @@ def test_against_committed_golden(cuda):
                      ddpm_noise=[n.to(cuda) for n in gold["ddpm_noise"]], record_latents=True)
     derr = [(a.cpu() - b).abs().max().item() for a, b in zip(dres["latents"], gold["ddpm_latents"])]
     assert max(derr) <= 0.1, derr
+
+
+def test_diffusers_dialect_controlnet_and_unet(cuda):
+    """The diffusers surface (UNet2DConditionModel / ControlNetModel.from_unet, diffusers kwargs through
+    sample_from_controlnet / sample_from_ldm, diffusers-named state dicts with Linear proj_in/proj_out) against the
+    oracle fed the translated weights; Transformer2DModel's GroupNorm eps is 1e-6 whatever norm_eps says."""
+    from ccnet_amd import diffusers_dialect as dd
+    from ccnet_amd.nets import adjust_class_embedding
+    from ccnet_amd.sampling import sample_from_controlnet, sample_from_ldm
+    from ccnet_amd.synthetic import init_weights
+    import oracle.nets as on
+    dcfg = dict(block_out_channels=(64, 128), down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), layers_per_block=1,
+                cross_attention_dim=64, attention_head_dim=(1, 2), use_linear_projection=True, norm_eps=1e-5)
+    un = dd.UNet2DConditionModel(**dcfg)
+    adjust_class_embedding(un)                      # util.py:1302 (cond_on_acq_times)
+    init_weights(un._net, 31)
+    un.config.num_class_embeds = None               # util.py:1337-1340
+    cn = dd.ControlNetModel.from_unet(un, conditioning_channels=1)
+    un.config.num_class_embeds = 99999
+    adjust_class_embedding(cn)
+    init_weights(cn._net, 32)
+    un, cn = un.to(cuda).eval(), cn.to(cuda).eval()
+    # oracle twins: monai-generative modules, weights through the key translation, transformer GroupNorm eps 1e-6
+    ou = on.DiffusionModelUNet(out_channels=4, **TINY)
+    oc = on.ControlNet(**TINY, **TINY_CE)
+    for o, d in ((ou, un), (oc, cn)):
+        on.adjust_class_embedding(o)
+        o.load_state_dict(dd.state_dict_to_monai({k: v.cpu() for k, v in d.state_dict().items()}))
+        n = 0
+        for m in o.modules():
+            if type(m).__name__ == "SpatialTransformer":
+                m.norm.eps = 1e-6
+                n += 1
+        assert n > 0
+        o.eval()
+    x, ctx, cond = _inputs(2, cuda, seed=33)
+    t = torch.tensor([320])
+    acq = torch.tensor([[100.0, 700.0]])            # (1, bs): reshaped by sample_from_* as in the reference
+    down, mid = sample_from_controlnet(cn, x.to(cuda), cond.to(cuda), t.to(cuda), ctx.to(cuda), class_labels=acq.to(cuda),
+                                       conditioning_scale=0.8)
+    out = sample_from_ldm(un, x.to(cuda), t.to(cuda), ctx.to(cuda), down, mid, class_labels=acq.to(cuda))
+    plain = sample_from_ldm(un, x.to(cuda), t.to(cuda), ctx.to(cuda), class_labels=acq.to(cuda))
+    with torch.no_grad():
+        a = acq.reshape(2, 1)
+        rd, rm = oc(x, t, cond, 0.8, ctx, a)
+        ref = ou(x, t, ctx, a, rd, rm)
+        ref_plain = ou(x, t, ctx, a)
+    assert isinstance(down, tuple) and len(down) == len(rd)
+    _check(mid.float(), rm, "diffusers-dialect controlnet mid")
+    _check(out, ref, "diffusers-dialect unet + residuals")
+    _check(plain, ref_plain, "diffusers-dialect unet")
+    r = un(sample=x.to(cuda), timestep=320, encoder_hidden_states=ctx.to(cuda), class_labels=acq.reshape(2, 1).to(cuda))
+    assert torch.equal(r.sample, plain)             # python-number timestep, return_dict=True
