@@ -392,3 +392,161 @@ def load_ccnet_checkpoint(path: str, model: nn.Module, key: str):
     sd = ckpt[key] if isinstance(ckpt, dict) and key in ckpt and isinstance(ckpt[key], dict) else ckpt
     model.load_state_dict(sd)
     return model
+
+
+# ------------------------------------------------------------------------------------------------ SD-VAE
+@dataclass
+class DecoderOutput:
+    sample: torch.Tensor
+
+
+class DiagonalGaussianDistribution:
+    """Posterior of `AutoencoderKL.encode` (what `Stage1Wrapper.forward` samples, util.py:1484-1487)."""
+
+    def __init__(self, mean: torch.Tensor, std: torch.Tensor):
+        self.mean, self.std = mean, std
+        self.var = std * std
+        self.logvar = 2.0 * torch.log(std)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * eps
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+    def kl(self) -> torch.Tensor:
+        return 0.5 * torch.sum(self.mean ** 2 + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: DiagonalGaussianDistribution
+
+
+_VAE_DEFAULTS = dict(
+    in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",), up_block_types=("UpDecoderBlock2D",),
+    block_out_channels=(64,), layers_per_block=1, act_fn="silu", latent_channels=4, norm_num_groups=32, sample_size=32,
+    scaling_factor=0.18215, shift_factor=None, latents_mean=None, latents_std=None, force_upcast=True,
+    use_quant_conv=True, use_post_quant_conv=True, mid_block_add_attention=True)
+
+_RES_D2M = {"conv1.": "conv1.conv.", "conv2.": "conv2.conv.", "conv_shortcut.": "nin_shortcut.conv."}
+_ATT_D2M = {"group_norm.": "norm.", "to_out.0.": "proj_attn.",
+            # pre-0.18 checkpoints of the same block
+            "query.": "to_q.", "key.": "to_k.", "value.": "to_v."}
+
+
+class AutoencoderKL(_DiffusersNet):
+    """diffusers `AutoencoderKL` (the SD-VAE the reference loads with `AutoencoderKL.from_pretrained(source_model,
+    subfolder="vae")`, util.py:1215,1227) over the lowered autoencoder: `encode(x).latent_dist`, `decode(z).sample`,
+    diffusers-named state dict (`encoder.down_blocks.i.resnets.j...`, `quant_conv`, ...)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cfg = dict(_VAE_DEFAULTS)
+        cfg.update({k: v for k, v in kwargs.items() if k in _VAE_DEFAULTS})
+        boc = list(cfg["block_out_channels"])
+        n = len(boc)
+        if list(cfg["down_block_types"]) != ["DownEncoderBlock2D"] * n or \
+                list(cfg["up_block_types"]) != ["UpDecoderBlock2D"] * n or cfg["act_fn"] not in ("silu", "swish") or \
+                not cfg["use_quant_conv"] or not cfg["use_post_quant_conv"]:
+            raise NotImplementedError("AutoencoderKL option outside the SD-VAE family")
+        lpb, lat = cfg["layers_per_block"], cfg["latent_channels"]
+        mid = bool(cfg["mid_block_add_attention"])
+        net = nets.AutoencoderKL(
+            spatial_dims=2, in_channels=cfg["in_channels"], out_channels=cfg["out_channels"], num_res_blocks=lpb,
+            num_channels=boc, attention_levels=[False] * n, latent_channels=lat,
+            norm_num_groups=cfg["norm_num_groups"], norm_eps=1e-6, with_encoder_nonlocal_attn=mid,
+            with_decoder_nonlocal_attn=mid, _decoder_num_res_blocks=lpb + 1, _final_act=True,
+            _encoder_out_channels=2 * lat)
+        if not mid:
+            raise NotImplementedError("mid_block_add_attention=False")
+        object.__setattr__(self, "config", FrozenConfig(cfg))
+        self._net = net
+        # (diffusers prefix, lowered prefix, kind) for every block of the flat encoder / decoder lists
+        m: List[Tuple[str, str, str]] = []
+        for side, nres, blocks in (("encoder", lpb, net.encoder.blocks), ("decoder", lpb + 1, net.decoder.blocks)):
+            i = 0
+            m.append((f"{side}.conv_in.", f"{side}.blocks.0.conv.", "conv"))
+            i = 1
+            if side == "decoder":
+                for nm, kind in (("resnets.0", "res"), ("attentions.0", "attn"), ("resnets.1", "res")):
+                    m.append((f"decoder.mid_block.{nm}.", f"decoder.blocks.{i}.", kind))
+                    i += 1
+            grp = "down_blocks" if side == "encoder" else "up_blocks"
+            smp = "downsamplers" if side == "encoder" else "upsamplers"
+            for lvl in range(n):
+                for j in range(nres):
+                    m.append((f"{side}.{grp}.{lvl}.resnets.{j}.", f"{side}.blocks.{i}.", "res"))
+                    i += 1
+                if lvl != n - 1:
+                    m.append((f"{side}.{grp}.{lvl}.{smp}.0.conv.", f"{side}.blocks.{i}.conv.conv.", "conv"))
+                    i += 1
+            if side == "encoder":
+                for nm, kind in (("resnets.0", "res"), ("attentions.0", "attn"), ("resnets.1", "res")):
+                    m.append((f"encoder.mid_block.{nm}.", f"encoder.blocks.{i}.", kind))
+                    i += 1
+            m.append((f"{side}.conv_norm_out.", f"{side}.blocks.{i}.", "norm"))
+            m.append((f"{side}.conv_out.", f"{side}.blocks.{i + 1}.conv.", "conv"))
+            assert i + 2 == len(blocks)
+        m.append(("post_quant_conv.", "post_quant_conv.conv.", "conv"))
+        self._map = m
+
+    # ---- state dict in diffusers names
+    def _leaf(self, rest: str, kind: str, to_monai: bool) -> str:
+        table = _RES_D2M if kind == "res" else _ATT_D2M if kind == "attn" else {}
+        for d, mm in table.items():
+            a, b = (d, mm) if to_monai else (mm, d)
+            if rest.startswith(a) and (to_monai or d in ("conv1.", "conv2.", "conv_shortcut.", "group_norm.", "to_out.0.")):
+                return b + rest[len(a):]
+        return rest
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = self._net.state_dict(keep_vars=keep_vars)
+        out = destination if destination is not None else {}
+        for dp, mp, kind in self._map:
+            for k, v in sd.items():
+                if k.startswith(mp):
+                    out[prefix + dp + self._leaf(k[len(mp):], kind, False)] = v
+        for leaf in ("weight", "bias"):  # quant_conv: rows [mean | logvar]
+            out[prefix + "quant_conv." + leaf] = torch.cat([sd[f"quant_conv_mu.conv.{leaf}"],
+                                                            sd[f"quant_conv_log_sigma.conv.{leaf}"]], 0)
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd, out = dict(state_dict), {}
+        lat = self.config.latent_channels
+        for leaf in ("weight", "bias"):
+            q = sd.pop(f"quant_conv.{leaf}", None)
+            if q is not None:
+                out[f"quant_conv_mu.conv.{leaf}"], out[f"quant_conv_log_sigma.conv.{leaf}"] = q[:lat], q[lat:]
+        for k, v in sd.items():
+            for dp, mp, kind in self._map:
+                if k.startswith(dp):
+                    mk = mp + self._leaf(k[len(dp):], kind, True)
+                    if kind == "attn" and v.dim() == 4:  # very old checkpoints stored the attention Linears as 1x1 convs
+                        v = v[:, :, 0, 0]
+                    out[mk] = v
+                    break
+            else:
+                out[k] = v  # unknown key: let nn.Module report it
+        return self._net.load_state_dict(out, strict=strict, **kw)
+
+    # ---- diffusers call surface
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        mean, std = self._net.encode(x)
+        post = DiagonalGaussianDistribution(mean, std)
+        return AutoencoderKLOutput(latent_dist=post) if return_dict else (post,)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
+        dec = self._net.decode(z)
+        return DecoderOutput(sample=dec) if return_dict else (dec,)
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True,
+                generator: Optional[torch.Generator] = None):
+        post = self.encode(sample).latent_dist
+        z = post.sample(generator=generator) if sample_posterior else post.mode()
+        return self.decode(z, return_dict=return_dict)

@@ -689,6 +689,19 @@ def _ae_resblock(cin, cout, groups, eps) -> _Holder:
     return h
 
 
+def _ae_attention(ch, groups, eps) -> _Holder:
+    """AttentionBlock of the autoencoder: one head over all channels (num_head_channels=None), Linear q/k/v/proj with
+    bias, residual connection."""
+    h = _Holder()
+    h.norm = nn.GroupNorm(groups, ch, eps=eps, affine=True)
+    h.to_q = nn.Linear(ch, ch)
+    h.to_k = nn.Linear(ch, ch)
+    h.to_v = nn.Linear(ch, ch)
+    h.proj_attn = nn.Linear(ch, ch)
+    h.kind, h.ch = "attn", ch
+    return h
+
+
 def _ae_sample(ch, kind) -> _Holder:
     h = _Holder()
     h.conv = _convolution(ch, ch, 3, 2 if kind == "down" else 1, 0 if kind == "down" else 1)
@@ -703,22 +716,26 @@ class AutoencoderKL(nn.Module):
                  num_channels=(32, 64, 64, 64), attention_levels=(False, False, True, True),
                  latent_channels: int = 3, norm_num_groups: int = 32, norm_eps: float = 1e-6,
                  with_encoder_nonlocal_attn: bool = True, with_decoder_nonlocal_attn: bool = True,
-                 use_flash_attention: bool = False):
+                 use_flash_attention: bool = False, _decoder_num_res_blocks=None, _final_act: bool = False,
+                 _encoder_out_channels: Optional[int] = None):
+        """The three underscore options are not monai-generative's: they let `ccnet_amd.diffusers_dialect.AutoencoderKL`
+        express the SD-VAE on the same block list (decoder levels with layers_per_block + 1 resnets, SiLU after the
+        final GroupNorm of encoder and decoder, an encoder that emits 2 x latent_channels moments)."""
         super().__init__()
         if spatial_dims != 2:
             raise NotImplementedError("only spatial_dims=2")
-        if any(attention_levels) or with_encoder_nonlocal_attn or with_decoder_nonlocal_attn:
-            raise NotImplementedError("AutoencoderKL attention blocks are not lowered: every ccnet stage-1 config "
-                                      "(configs/stage1/aekl_v0.yaml:14-16) disables them")
-        if in_channels > 8 or out_channels > 8 or latent_channels > 8:
+        if in_channels > 8 or out_channels > 8 or latent_channels > 8 or (_encoder_out_channels or 0) > 8:
             raise CcnetError("in/out/latent channels > 8 are not lowered")
         if any(c % 64 for c in num_channels):
             raise CcnetError("the MI355X lowering needs every entry of num_channels to be a multiple of 64")
         n = len(num_channels)
         nrb = _tuple(num_res_blocks, n)
+        att = _tuple(attention_levels, n)
         self.num_channels = list(num_channels)
         self.latent_channels, self.in_channels, self.out_channels = latent_channels, in_channels, out_channels
         self.norm_num_groups, self.norm_eps = norm_num_groups, norm_eps
+        self.final_act = bool(_final_act)
+        enc_out = _encoder_out_channels or latent_channels
         g, eps = norm_num_groups, norm_eps
         # encoder.blocks / decoder.blocks are flat lists upstream (keys `encoder.blocks.{i}....`)
         enc = [_convolution(in_channels, num_channels[0])]
@@ -728,29 +745,39 @@ class AutoencoderKL(nn.Module):
             for _ in range(nrb[i]):
                 enc.append(_ae_resblock(in_ch, out_ch, g, eps))
                 in_ch = out_ch
+                if att[i]:
+                    enc.append(_ae_attention(in_ch, g, eps))
             if i != n - 1:
                 enc.append(_ae_sample(in_ch, "down"))
+        if with_encoder_nonlocal_attn:
+            cl = num_channels[-1]
+            enc += [_ae_resblock(cl, cl, g, eps), _ae_attention(cl, g, eps), _ae_resblock(cl, cl, g, eps)]
         enc.append(nn.GroupNorm(g, num_channels[-1], eps=eps, affine=True))
-        enc.append(_convolution(num_channels[-1], latent_channels))
+        enc.append(_convolution(num_channels[-1], enc_out))
         self.encoder = _Holder()
         self.encoder.blocks = nn.ModuleList(enc)
         rev = list(reversed(num_channels))
-        rev_res = list(reversed(nrb))
+        rev_res = list(reversed(_tuple(_decoder_num_res_blocks, n) if _decoder_num_res_blocks is not None else nrb))
+        rev_att = list(reversed(att))
         dec = [_convolution(latent_channels, rev[0])]
+        if with_decoder_nonlocal_attn:
+            dec += [_ae_resblock(rev[0], rev[0], g, eps), _ae_attention(rev[0], g, eps), _ae_resblock(rev[0], rev[0], g, eps)]
         out_ch = rev[0]
         for i in range(n):
             in_ch, out_ch = out_ch, rev[i]
             for _ in range(rev_res[i]):
                 dec.append(_ae_resblock(in_ch, out_ch, g, eps))
                 in_ch = out_ch
+                if rev_att[i]:
+                    dec.append(_ae_attention(in_ch, g, eps))
             if i != n - 1:
                 dec.append(_ae_sample(in_ch, "up"))
         dec.append(nn.GroupNorm(g, in_ch, eps=eps, affine=True))
         dec.append(_convolution(in_ch, out_channels))
         self.decoder = _Holder()
         self.decoder.blocks = nn.ModuleList(dec)
-        self.quant_conv_mu = _convolution(latent_channels, latent_channels, 1, 1, 0)
-        self.quant_conv_log_sigma = _convolution(latent_channels, latent_channels, 1, 1, 0)
+        self.quant_conv_mu = _convolution(enc_out, latent_channels, 1, 1, 0)
+        self.quant_conv_log_sigma = _convolution(enc_out, latent_channels, 1, 1, 0)
         self.post_quant_conv = _convolution(latent_channels, latent_channels, 1, 1, 0)
         self._pk = None
 
@@ -787,6 +814,12 @@ class AutoencoderKL(nn.Module):
                         "n1": (f32(b.norm1.weight), f32(b.norm1.bias)), "n2": (f32(b.norm2.weight), f32(b.norm2.bias)),
                         "c1": pconv(b.conv1.conv), "c2": pconv(b.conv2.conv), "cout": b.cout,
                         "skip": None if isinstance(b.nin_shortcut, nn.Identity) else pconv(b.nin_shortcut.conv)}))
+                elif getattr(b, "kind", None) == "attn":
+                    qkv = torch.cat([b.to_q.weight, b.to_k.weight, b.to_v.weight], 0).detach()
+                    lst.append(("attn", {
+                        "norm": (f32(b.norm.weight), f32(b.norm.bias)), "ch": b.ch,
+                        "qkv": (qkv.to(dev, BF16).contiguous(), f32(torch.cat([b.to_q.bias, b.to_k.bias, b.to_v.bias]))),
+                        "proj": (b.proj_attn.weight.detach().to(dev, BF16).contiguous(), f32(b.proj_attn.bias))}))
                 elif getattr(b, "kind", None) in ("down", "up"):
                     lst.append((b.kind,) + pconv(b.conv.conv))
                 elif i == 0:  # first conv: tiny Cin, fp32 direct kernel
@@ -821,8 +854,20 @@ class AutoencoderKL(nn.Module):
                 h = ops.conv(h, item[1], item[2], h.C, R=3, stride=2, pad=0, out_hw=(h.H // 2, h.W // 2))
             elif kind == "up":
                 h = ops.conv(h, item[1], item[2], h.C, R=3, ups=2)
-            elif kind == "norm":  # upstream applies no nonlinearity after the final GroupNorm
-                h = ops.groupnorm(h, item[1], item[2], g, eps, False)
+            elif kind == "attn":
+                p = item[1]
+                C_, T = p["ch"], h.H * h.W
+                if C_ % 64:
+                    raise CcnetError(f"autoencoder attention over {C_} channels: the MI355X lowering needs a multiple of 64")
+                t = ops.groupnorm(h, p["norm"][0], p["norm"][1], g, eps, False).t
+                qkv = ops.linear(t, p["qkv"][0], p["qkv"][1], 3 * C_, C_)
+                q, k, v = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
+                sc = 1.0 / math.sqrt(C_)
+                o = ops.attention_d64(q, k, v, h.N, 1, T, T, sc) if C_ == 64 else \
+                    ops.attention_generic(q, k, v, h.N, 1, T, T, C_, sc)
+                h = Act(ops.linear(o, p["proj"][0], p["proj"][1], C_, C_, res1=h.t), h.N, h.H, h.W, C_)
+            elif kind == "norm":  # monai-generative applies no nonlinearity after the final GroupNorm, diffusers a SiLU
+                h = ops.groupnorm(h, item[1], item[2], g, eps, self.final_act)
             elif kind == "conv_last":
                 return ops.conv_out_small(h, item[1], item[2], item[3])
         raise CcnetError("malformed AutoencoderKL block list")

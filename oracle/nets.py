@@ -472,9 +472,23 @@ class AEUpsample(nn.Module):
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
+class _SiLUAfter(nn.Module):
+    """GroupNorm followed by SiLU (diffusers Encoder/Decoder: conv_norm_out -> conv_act); keeps the GroupNorm's
+    parameter names (`weight`, `bias`) so the state dict does not change."""
+
+    def __init__(self, groups, ch, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ch))
+        self.bias = nn.Parameter(torch.zeros(ch))
+        self.groups, self.eps = groups, eps
+
+    def forward(self, x):
+        return F.silu(F.group_norm(x, self.groups, self.weight, self.bias, self.eps))
+
+
 class AEEncoder(nn.Module):
     def __init__(self, in_channels, num_channels, out_channels, num_res_blocks, groups, eps, attention_levels,
-                 with_nonlocal_attn):
+                 with_nonlocal_attn, final_act=False):
         super().__init__()
         blocks = [Convolution(in_channels, num_channels[0])]
         out_ch = num_channels[0]
@@ -491,7 +505,8 @@ class AEEncoder(nn.Module):
             blocks += [AEResBlock(num_channels[-1], num_channels[-1], groups, eps),
                        AEAttentionBlock(num_channels[-1], groups, eps),
                        AEResBlock(num_channels[-1], num_channels[-1], groups, eps)]
-        blocks.append(nn.GroupNorm(groups, num_channels[-1], eps=eps, affine=True))
+        blocks.append(_SiLUAfter(groups, num_channels[-1], eps) if final_act else
+                      nn.GroupNorm(groups, num_channels[-1], eps=eps, affine=True))
         blocks.append(Convolution(num_channels[-1], out_channels))
         self.blocks = nn.ModuleList(blocks)
 
@@ -503,7 +518,7 @@ class AEEncoder(nn.Module):
 
 class AEDecoder(nn.Module):
     def __init__(self, num_channels, in_channels, out_channels, num_res_blocks, groups, eps, attention_levels,
-                 with_nonlocal_attn):
+                 with_nonlocal_attn, final_act=False):
         super().__init__()
         rev = list(reversed(num_channels))
         blocks = [Convolution(in_channels, rev[0])]
@@ -522,7 +537,7 @@ class AEDecoder(nn.Module):
                     blocks.append(AEAttentionBlock(in_ch, groups, eps))
             if i != len(rev) - 1:
                 blocks.append(AEUpsample(in_ch))
-        blocks.append(nn.GroupNorm(groups, in_ch, eps=eps, affine=True))
+        blocks.append(_SiLUAfter(groups, in_ch, eps) if final_act else nn.GroupNorm(groups, in_ch, eps=eps, affine=True))
         blocks.append(Convolution(in_ch, out_channels))
         self.blocks = nn.ModuleList(blocks)
 
@@ -537,19 +552,26 @@ class AutoencoderKL(nn.Module):
                  num_channels=(32, 64, 64, 64), attention_levels=(False, False, True, True),
                  latent_channels: int = 3, norm_num_groups: int = 32, norm_eps: float = 1e-6,
                  with_encoder_nonlocal_attn: bool = True, with_decoder_nonlocal_attn: bool = True,
-                 use_flash_attention: bool = False):
+                 use_flash_attention: bool = False, _decoder_num_res_blocks=None, _final_act: bool = False,
+                 _encoder_out_channels=None):
+        """Underscore options: the diffusers SD-VAE (`diffusers.models.autoencoders.vae.Encoder/Decoder`, 0.32.0) on the
+        same block list -- decoder levels with layers_per_block + 1 resnets, SiLU after conv_norm_out, an encoder
+        emitting 2 x latent_channels moments that `quant_conv` (here its mean rows / logvar rows) maps to the posterior."""
         super().__init__()
         assert spatial_dims == 2
         n = len(num_channels)
         nrb = _tuple(num_res_blocks, n)
+        dnrb = _tuple(_decoder_num_res_blocks, n) if _decoder_num_res_blocks is not None else nrb
+        att = _tuple(attention_levels, n)
+        enc_out = _encoder_out_channels or latent_channels
         self.num_channels = list(num_channels)
         self.latent_channels = latent_channels
-        self.encoder = AEEncoder(in_channels, num_channels, latent_channels, nrb, norm_num_groups, norm_eps,
-                                 attention_levels, with_encoder_nonlocal_attn)
-        self.decoder = AEDecoder(num_channels, latent_channels, out_channels, nrb, norm_num_groups, norm_eps,
-                                 attention_levels, with_decoder_nonlocal_attn)
-        self.quant_conv_mu = Convolution(latent_channels, latent_channels, kernel_size=1, padding=0)
-        self.quant_conv_log_sigma = Convolution(latent_channels, latent_channels, kernel_size=1, padding=0)
+        self.encoder = AEEncoder(in_channels, num_channels, enc_out, nrb, norm_num_groups, norm_eps,
+                                 att, with_encoder_nonlocal_attn, _final_act)
+        self.decoder = AEDecoder(num_channels, latent_channels, out_channels, dnrb, norm_num_groups, norm_eps,
+                                 att, with_decoder_nonlocal_attn, _final_act)
+        self.quant_conv_mu = Convolution(enc_out, latent_channels, kernel_size=1, padding=0)
+        self.quant_conv_log_sigma = Convolution(enc_out, latent_channels, kernel_size=1, padding=0)
         self.post_quant_conv = Convolution(latent_channels, latent_channels, kernel_size=1, padding=0)
 
     def encode(self, x):

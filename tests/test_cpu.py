@@ -404,3 +404,53 @@ def test_diffusers_dialect_from_pretrained_local_folder(tmp_path):
     x = dd.load_ccnet_checkpoint(str(tmp_path / "bare.pt"), dd.UNet2DConditionModel(**tiny), "diffusion")
     for m in (w, x):
         assert all(torch.equal(a[k], m._net.state_dict()[k]) for k in a)
+
+
+def test_diffusers_dialect_sd_vae_keys_and_round_trip():
+    """SD-VAE (`stabilityai/stable-diffusion-2-1-base/vae`): 248 tensors, 83,653,863 parameters (published figure)."""
+    from ccnet_amd import diffusers_dialect as dd
+    sdvae = dict(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                 up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[128, 256, 512, 512], layers_per_block=2,
+                 latent_channels=4, norm_num_groups=32, sample_size=768, scaling_factor=0.18215)
+    with torch.device("meta"):
+        v = dd.AutoencoderKL(**sdvae)
+    sd = v.state_dict()
+    assert len(sd) == 248 and sum(t.numel() for t in sd.values()) == 83_653_863
+    for k, shape in {"encoder.conv_in.weight": (128, 3, 3, 3), "encoder.mid_block.attentions.0.to_q.weight": (512, 512),
+                     "encoder.mid_block.attentions.0.group_norm.weight": (512,), "encoder.conv_out.weight": (8, 512, 3, 3),
+                     "quant_conv.weight": (8, 8, 1, 1), "post_quant_conv.bias": (4,),
+                     "decoder.up_blocks.0.resnets.2.conv1.weight": (512, 512, 3, 3),
+                     "decoder.up_blocks.2.resnets.0.conv_shortcut.weight": (256, 512, 1, 1),
+                     "decoder.up_blocks.3.resnets.2.norm2.bias": (128,), "decoder.conv_out.weight": (3, 128, 3, 3)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in sd and v.config.scaling_factor == 0.18215
+    tiny = dict(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 2,
+                up_block_types=["UpDecoderBlock2D"] * 2, block_out_channels=[64, 128], layers_per_block=1)
+    a = dd.AutoencoderKL(**tiny)
+    for p in a.parameters():
+        p.data.normal_()
+    sd = a.state_dict()
+    b = dd.AutoencoderKL(**tiny)
+    b.load_state_dict(sd)
+    # pre-0.18 spelling of the attention block (query/key/value/proj_attn) loads too
+    old = {k.replace(".to_q.", ".query.").replace(".to_k.", ".key.").replace(".to_v.", ".value.")
+            .replace(".to_out.0.", ".proj_attn."): v for k, v in sd.items()}
+    c = dd.AutoencoderKL(**tiny)
+    c.load_state_dict(old)
+    x, y, z = a._net.state_dict(), b._net.state_dict(), c._net.state_dict()
+    assert all(torch.equal(x[k], y[k]) and torch.equal(x[k], z[k]) for k in x)
+    with pytest.raises(RuntimeError):
+        b.load_state_dict({**sd, "decoder.bogus.weight": torch.zeros(1)})
+
+
+def test_autoencoder_attention_state_dict_matches_oracle():
+    import ccnet_amd.nets as pn
+    import oracle.nets as on
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[64, 128], latent_channels=4,
+               num_res_blocks=1, attention_levels=[False, True], with_encoder_nonlocal_attn=True,
+               with_decoder_nonlocal_attn=True)
+    for extra in ({}, dict(_decoder_num_res_blocks=2, _final_act=True, _encoder_out_channels=8)):
+        p, o = pn.AutoencoderKL(**cfg, **extra), on.AutoencoderKL(**cfg, **extra)
+        a, b = p.state_dict(), o.state_dict()
+        assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+        assert any(".to_q." in k for k in a)

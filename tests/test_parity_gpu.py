@@ -275,3 +275,51 @@ def test_diffusers_dialect_controlnet_and_unet(cuda):
     _check(plain, ref_plain, "diffusers-dialect unet")
     r = un(sample=x.to(cuda), timestep=320, encoder_hidden_states=ctx.to(cuda), class_labels=acq.reshape(2, 1).to(cuda))
     assert torch.equal(r.sample, plain)             # python-number timestep, return_dict=True
+
+
+def test_vae_attention_blocks_and_sd_vae_dialect(cuda):
+    """Autoencoder attention blocks (monai-generative AttentionBlock: one head over all channels) and the SD-VAE
+    surface of diffusers (`encode(x).latent_dist`, `decode(z).sample`, 3-resnet decoder levels, SiLU after the final
+    GroupNorm, `quant_conv` on 2 x latent moments) against the oracle on translated weights."""
+    from ccnet_amd import diffusers_dialect as dd
+    from ccnet_amd.synthetic import init_weights
+    import oracle.nets as on
+    # (1) monai-generative kwargs with attention at the last level and both non-local blocks
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[64, 128], latent_channels=4,
+               num_res_blocks=1, attention_levels=[False, True], with_encoder_nonlocal_attn=True,
+               with_decoder_nonlocal_attn=True)
+    p, o = build_pair("vae", cfg, 41, cuda)
+    g = torch.Generator().manual_seed(42)
+    z = torch.randn(2, 4, 16, 16, generator=g)
+    x = torch.rand(2, 1, 32, 32, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref = o.decode(z)
+        rmu, rsig = o.encode(x)
+    out = p.decode(z.to(cuda))
+    mu, sig = p.encode(x.to(cuda))
+    _check(out, ref, "AEKL decode with attention")
+    _check(mu, rmu, "AEKL encode mu with attention")
+    _check(sig, rsig, "AEKL encode sigma with attention")
+    # (2) diffusers SD-VAE dialect
+    tiny = dict(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 2,
+                up_block_types=["UpDecoderBlock2D"] * 2, block_out_channels=[64, 128], layers_per_block=1,
+                latent_channels=4)
+    v = dd.AutoencoderKL(**tiny)
+    init_weights(v._net, 43)
+    ov = on.AutoencoderKL(spatial_dims=2, in_channels=3, out_channels=3, num_channels=[64, 128], latent_channels=4,
+                          num_res_blocks=1, attention_levels=[False, False], with_encoder_nonlocal_attn=True,
+                          with_decoder_nonlocal_attn=True, norm_eps=1e-6, _decoder_num_res_blocks=2, _final_act=True,
+                          _encoder_out_channels=8)
+    ov.load_state_dict(v._net.state_dict())
+    v = v.to(cuda).eval()
+    x3 = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref = ov.decode(z)
+        rmu, rsig = ov.encode(x3)
+    dec = v.decode(z.to(cuda))
+    post = v.encode(x3.to(cuda)).latent_dist
+    _check(dec.sample, ref, "SD-VAE decode")
+    _check(post.mean, rmu, "SD-VAE posterior mean")
+    _check(post.std, rsig, "SD-VAE posterior std")
+    assert torch.equal(post.mode(), post.mean) and post.sample().shape == rmu.shape
+    assert torch.allclose(post.logvar, 2 * torch.log(post.std))
