@@ -219,7 +219,9 @@ class Sampler:
             res["latents"] = trace
         if decode and self.stage1 is not None:
             # run_controlnet_inference.py:255-256
-            res["image"] = self.stage1.decode(x / self.scale_factor)
+            img = self.stage1.decode(x / self.scale_factor)
+            # diffusers' AutoencoderKL returns DecoderOutput; the reference unwraps `.sample` when saving (util.py:1402)
+            res["image"] = getattr(img, "sample", img)
         return res
 
 

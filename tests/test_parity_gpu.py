@@ -323,3 +323,61 @@ def test_vae_attention_blocks_and_sd_vae_dialect(cuda):
     _check(post.std, rsig, "SD-VAE posterior std")
     assert torch.equal(post.mode(), post.mean) and post.sample().shape == rmu.shape
     assert torch.allclose(post.logvar, 2 * torch.log(post.std))
+
+
+def test_sampler_on_the_diffusers_surface(cuda):
+    """run_controlnet_inference.py:211-256 with the classes the reference's SD-2.1 path builds: UNet2DConditionModel,
+    ControlNetModel.from_unet, diffusers AutoencoderKL (decode returns `.sample`), DDIM, CFG, acquisition times."""
+    import ccnet_amd.schedulers as ps
+    import oracle.nets as on
+    import oracle.schedulers as osch
+    from ccnet_amd import diffusers_dialect as dd
+    from ccnet_amd.nets import adjust_class_embedding
+    from ccnet_amd.sampling import Sampler
+    from ccnet_amd.synthetic import init_weights
+    from oracle.sampler import sample as osample
+    dcfg = dict(block_out_channels=(64, 128), down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), layers_per_block=1,
+                cross_attention_dim=64, attention_head_dim=(1, 2), use_linear_projection=True, norm_eps=1e-5)
+    un = dd.UNet2DConditionModel(**dcfg)
+    cn = dd.ControlNetModel.from_unet(un, conditioning_channels=1)
+    for m, seed in ((un, 51), (cn, 52)):
+        adjust_class_embedding(m)
+        init_weights(m._net, seed)
+    vae = dd.AutoencoderKL(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                           up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[64, 64, 128, 128],
+                           layers_per_block=1, latent_channels=4)
+    init_weights(vae._net, 53)
+    ou, oc = on.DiffusionModelUNet(out_channels=4, **TINY), on.ControlNet(**TINY, **TINY_CE)
+    for o, d in ((ou, un), (oc, cn)):
+        on.adjust_class_embedding(o)
+        o.load_state_dict(dd.state_dict_to_monai(d.state_dict()))
+        for m in o.modules():
+            if type(m).__name__ == "SpatialTransformer":
+                m.norm.eps = 1e-6
+        o.eval()
+    ov = on.AutoencoderKL(spatial_dims=2, in_channels=3, out_channels=3, num_channels=[64, 64, 128, 128],
+                          latent_channels=4, num_res_blocks=1, attention_levels=[False] * 4,
+                          with_encoder_nonlocal_attn=True, with_decoder_nonlocal_attn=True, norm_eps=1e-6,
+                          _decoder_num_res_blocks=2, _final_act=True, _encoder_out_channels=8).eval()
+    ov.load_state_dict(vae._net.state_dict())
+    un, cn, vae = un.to(cuda).eval(), cn.to(cuda).eval(), vae.to(cuda).eval()
+    B, steps = 2, 6
+    x, ctx, cond = _inputs(B, cuda, seed=54)
+    g = torch.Generator().manual_seed(55)
+    empty = 0.5 * torch.randn(1, 77, 64, generator=g)
+    acq = torch.tensor([250.0, 900.0])
+    psch, osc = ps.DDIMScheduler(clip_sample=False, **SCHED), osch.DDIMScheduler(clip_sample=False, **SCHED)
+    psch.set_timesteps(steps)
+    osc.set_timesteps(steps)
+    s = Sampler(cn, un, psch, vae, guidance_scale=3.0, conditioning_scale=1.0, scale_factor=0.5)
+    res = s.sample(x.to(cuda), cond.to(cuda), ctx.to(cuda), empty.to(cuda), acq.to(cuda), record_latents=True)
+    ref = osample(oc, ou, osc, x, cond, ctx, empty, guidance_scale=3.0, conditioning_scale=1.0,
+                  acquisition_time=acq, stage1=ov, scale_factor=0.5, record_latents=True)
+    errs = [(a.cpu() - b).abs().max().item() for a, b in zip(res["latents"], ref["latents"])]
+    print("diffusers-surface per-step latent max-abs:", " ".join(f"{e:.3e}" for e in errs))
+    assert max(errs) <= 0.1
+    assert res["image"].shape == (B, 3, 128, 128)
+    ps_db = psnr(res["image"], ref["image"])
+    print(f"diffusers-surface final image PSNR {ps_db:.1f} dB")
+    assert ps_db >= 40.0
