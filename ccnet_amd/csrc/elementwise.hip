@@ -383,6 +383,53 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* x, int N, in
     }
 }
 
+// Loader edge (util.py:123-128): uint8 image [N][H0][W0] (one channel) -> bicubic resize to H x W (the
+// F.interpolate(mode="bicubic", align_corners=False) arithmetic MONAI's Resized uses: A = -0.75, source index
+// scale * (dst + 0.5) - 0.5, taps clamped to the border) -> ScaleIntensityRanged [0,255] -> [-1,1] with clipping.
+// transpose = 1 reads the image as its transpose (MONAI's PNG reader hands the network a (W, H) array).
+__device__ __forceinline__ void cubic_weights(float t, float* w) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+    w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* src, int N, int H0, int W0, int transpose,
+                                                           float* out, int H, int W) {
+    // logical source image: Hs x Ws, element (y, x) = src[y][x] or src[x][y]
+    const int Hs = transpose ? W0 : H0, Ws = transpose ? H0 : W0;
+    const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % W), oy = (int)((i / W) % H);
+        const long long n = i / ((long long)W * H);
+        const float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+        const float iyf = floorf(fy), ixf = floorf(fx);
+        float wy[4], wx[4];
+        cubic_weights(fy - iyf, wy);
+        cubic_weights(fx - ixf, wx);
+        const int iy = (int)iyf, ix = (int)ixf;
+        const uint8_t* img = src + n * (long long)H0 * W0;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = min(max(iy - 1 + a, 0), Hs - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = min(max(ix - 1 + b, 0), Ws - 1);
+                const float v = (float)(transpose ? img[(long long)x * W0 + y] : img[(long long)y * W0 + x]);
+                row += wx[b] * v;
+            }
+            acc += wy[a] * row;
+        }
+        const float v = acc / 255.0f * 2.0f - 1.0f;
+        out[i] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
 // 1x1 convolution on <= 8 fp32 NCHW channels (AEKL quant / post-quant convs); mode 1 = exp(clamp(v,-30,20)/2)
 __global__ __launch_bounds__(256) void pointwise_nchw_kernel(const float* x, int N, int Cin, int HW, const float* w,
                                                              const float* b, int Cout, int mode, float* out) {
@@ -550,6 +597,15 @@ extern "C" int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return CCNET_EINVAL;
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for((long long)N * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, N,
                        C, HW, out);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_preprocess_u8_bicubic(const uint8_t* src, int N, int H0, int W0, int transpose, float* out, int H,
+                                           int W, void* stream) {
+    if (!src || !out || N <= 0 || H0 <= 0 || W0 <= 0 || H <= 0 || W <= 0) return CCNET_EINVAL;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((long long)N * H * W, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, N, H0, W0, transpose ? 1 : 0, out, H, W);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ.get("CCNET_HIP_LIB", str(_HERE / "libccnet_hip.so")))
 
 EXPORTS = [
     "ccnet_strerror", "ccnet_version", "ccnet_arch", "ccnet_conv_gemm_bf16", "ccnet_conv_in_small",
-    "ccnet_conv_out_small", "ccnet_groupnorm_workspace_bytes", "ccnet_groupnorm_bf16", "ccnet_layernorm_bf16",
+    "ccnet_conv_out_small", "ccnet_preprocess_u8_bicubic", "ccnet_groupnorm_workspace_bytes", "ccnet_groupnorm_bf16", "ccnet_layernorm_bf16",
     "ccnet_geglu_bf16", "ccnet_attention_d64_bf16", "ccnet_softmax_rows_bf16", "ccnet_timestep_embedding",
     "ccnet_linear_f32", "ccnet_cfg_scheduler_step", "ccnet_nchw_f32_to_nhwc_bf16", "ccnet_nhwc_bf16_to_nchw_f32",
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.ccnet_nchw_f32_to_nhwc_bf16.argtypes = [vp, i, i, i, vp, i, vp]
     lib.ccnet_nhwc_bf16_to_nchw_f32.argtypes = [vp, i, i, i, i, vp, vp]
     lib.ccnet_to_uint8.argtypes = [vp, i, i, i, vp, vp]
+    lib.ccnet_preprocess_u8_bicubic.argtypes = [vp, i, i, i, i, vp, i, i, vp]
     lib.ccnet_pointwise_nchw_f32.argtypes = [vp, i, i, i, vp, vp, i, i, vp, vp]
     lib.ccnet_axpy_f32.argtypes = [vp, vp, vp, C.c_longlong, vp, vp]
     lib.ccnet_set_option.argtypes = [i, i]

@@ -317,6 +317,20 @@ def to_uint8(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def preprocess_u8(img: torch.Tensor, H: int, W: int, transpose: bool = False) -> torch.Tensor:
+    """uint8 [N, H0, W0] -> bicubic resize to (H, W) -> [0,255] -> [-1,1] clipped; fp32 [N, 1, H, W] (util.py:123-128)."""
+    lib = _l.load()
+    _need_cuda(img)
+    if img.dtype != torch.uint8 or img.dim() != 3:
+        raise _l.CcnetError("preprocess_u8 expects a uint8 [N, H0, W0] tensor")
+    img = img.contiguous()
+    N, H0, W0 = img.shape
+    out = torch.empty((N, 1, H, W), dtype=torch.float32, device=img.device)
+    _l.check(lib.ccnet_preprocess_u8_bicubic(img.data_ptr(), N, H0, W0, int(transpose), out.data_ptr(), H, W, _stream()),
+             "preprocess_u8_bicubic")
+    return out
+
+
 def pointwise_nchw(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int) -> torch.Tensor:
     lib = _l.load()
     _need_cuda(x, w)

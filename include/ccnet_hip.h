@@ -165,6 +165,12 @@ int ccnet_pointwise_nchw_f32(const float* x, int N, int Cin, int HW, const float
                              const float* bias, int Cout, int mode, float* out, void* stream);
 int ccnet_axpy_f32(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
 
+/* Loader edge: LoadImaged -> Resized(mode="bicubic") -> ScaleIntensityRanged(0,255 -> -1,1, clip) (util.py:123-128).
+ * src uint8 [N][H0][W0] (single channel), out fp32 [N][1][H][W]; transpose != 0 reads each image as its transpose (what
+ * MONAI's PNG reader hands the network).  Bicubic arithmetic of F.interpolate(align_corners=False), A = -0.75. */
+int ccnet_preprocess_u8_bicubic(const uint8_t* src, int N, int H0, int W0, int transpose, float* out, int H, int W,
+                                void* stream);
+
 /* clip((x+1)/2,0,1) -> rint(*255) -> uint8 of channel 0 (util.py:1162-1173,1412-1416). x fp32 NCHW. */
 int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
 

@@ -357,3 +357,45 @@ def test_linear1_geglu_fused(cuda, rows, C):
     assert tuple(out.shape) == (rows, 4 * C)
     a, gate = F.linear(x.float(), w.float().to(cuda), b.to(cuda)).chunk(2, dim=-1)
     _close(out.float(), a * F.gelu(gate), atol=2e-2, what="linear1+geglu")
+
+
+def test_loader_and_writer_edges(cuda, tmp_path):
+    """Bicubic resize + intensity map against F.interpolate (the arithmetic MONAI's Resized(mode="bicubic") runs), and
+    the PIL / PIL_comparison writer against the reference's numpy recipe (util.py:1162-1173,1396-1447)."""
+    import numpy as np
+    from PIL import Image
+    from ccnet_amd import io as cio
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    for (H0, W0, H, W) in [(64, 64, 64, 64), (37, 53, 64, 48), (300, 280, 128, 128), (96, 80, 40, 56)]:
+        u8 = torch.randint(0, 256, (2, H0, W0), generator=g, dtype=torch.uint8)
+        for tr in (False, True):
+            src = u8.transpose(1, 2) if tr else u8
+            ref = F.interpolate(src[:, None].float().to(cuda), size=(H, W), mode="bicubic", align_corners=False)
+            ref = (ref / 255.0 * 2.0 - 1.0).clamp(-1.0, 1.0)
+            out = ops.preprocess_u8(u8.to(cuda), H, W, transpose=tr)
+            assert out.shape == ref.shape and (out - ref).abs().max().item() < 2e-5, (H0, W0, H, W, tr)
+    # PNG round trip through load_images: same-size images come back as x/127.5 - 1 of the transposed array
+    a = np.random.RandomState(3).randint(0, 256, (48, 32), dtype=np.uint8)
+    Image.fromarray(a).save(tmp_path / "src.png")
+    x = cio.load_images([tmp_path / "src.png"], 32, 48, device=cuda)
+    assert torch.allclose(x[0, 0].cpu(), torch.from_numpy(a.T.astype(np.float32)) / 127.5 - 1.0, atol=1e-6)
+    # writer
+    smp = torch.rand(2, 3, 16, 24, generator=g) * 2.4 - 1.2
+    cond = torch.rand(2, 1, 16, 24, generator=g) * 2 - 1
+    real = torch.rand(2, 1, 16, 24, generator=g) * 2 - 1
+    paths = cio.save_controlnet_inference_sample(tmp_path / "run", ["a.png", "b.png"], smp.to(cuda), cond.to(cuda), real.to(cuda))
+    assert [p.parent.name for p in paths] == ["PIL", "PIL", "PIL_comparison", "PIL_comparison"]
+
+    def ref_u8(t):  # interval_mapping(-1,1 -> 0,1, clipped) -> rint(*255), channel 0, float64 as the reference
+        v = np.clip((t.numpy().astype(np.float64) + 1.0) / 2.0, 0.0, 1.0)
+        return np.rint(v * 255).astype(np.uint8)[:, 0]
+    s8, c8, r8 = ref_u8(smp), ref_u8(cond), ref_u8(real)
+    for i, nm in enumerate(["a.png", "b.png"]):
+        got = np.asarray(Image.open(tmp_path / "run" / "PIL" / nm))
+        # fp32 vs float64 mapping may differ by one count on exact .5 ties only
+        assert got.shape == (16, 24) and np.abs(got.astype(int) - s8[i].astype(int)).max() <= 1
+        assert (got != s8[i]).mean() < 0.01
+        trip = np.asarray(Image.open(tmp_path / "run" / "PIL_comparison" / nm))
+        assert trip.shape == (16, 72) and np.abs(trip[:, :24].astype(int) - c8[i].astype(int)).max() <= 1
+        assert np.array_equal(trip[:, 24:48], got)
