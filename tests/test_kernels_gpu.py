@@ -399,3 +399,32 @@ def test_loader_and_writer_edges(cuda, tmp_path):
         trip = np.asarray(Image.open(tmp_path / "run" / "PIL_comparison" / nm))
         assert trip.shape == (16, 72) and np.abs(trip[:, :24].astype(int) - c8[i].astype(int)).max() <= 1
         assert np.array_equal(trip[:, 24:48], got)
+
+
+@pytest.mark.parametrize("rows,C,geglu", [(8192, 320, True), (8256, 320, True), (16384, 640, True), (24576, 1280, False),
+                                          (70000, 320, False)])
+def test_persistent_tile_loop_matches_one_tile_per_block(cuda, rows, C, geglu):
+    """Persistent launches (one block per CU walking tiles, next tile's stages issued before the epilogue, stores of a
+    tile draining under the next tile's first K-steps behind counted vmcnt waits) must give bit-identical results to
+    the same kernel launched one block per tile -- full and ragged tile grids, repeated to give a race a chance."""
+    from ccnet_amd import lib as _lib
+    ops = _ops()
+    l = _lib.load()
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(cuda)
+    Cout = 8 * C if geglu else (1280 if C == 1280 else 3 * C)
+    w = (torch.randn(Cout, C, generator=g) / math.sqrt(C)).to(torch.bfloat16).to(cuda)
+    b = (0.3 * torch.randn(Cout, generator=g)).to(cuda)
+    if geglu:
+        w, b = ops.geglu_interleave(w), ops.geglu_interleave(b)
+    try:
+        l.ccnet_set_option(4, 0)
+        ref = ops.linear(x, w, b, Cout, C, act=2 if geglu else 0).clone()
+        l.ccnet_set_option(4, 1)
+        for _ in range(6):
+            out = ops.linear(x, w, b, Cout, C, act=2 if geglu else 0)
+            assert torch.equal(out, ref)
+    finally:
+        l.ccnet_set_option(4, 1)
+    if not geglu:  # and against torch
+        _close(out.float(), F.linear(x.float(), w.float(), b), atol=3e-2, what="persistent linear")
