@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=0, help="force the split-K factor (0 = heuristic)")
     ap.add_argument("--order", type=int, default=-1, help="force tile order: 0 N-fastest, 1 M-fastest")
     ap.add_argument("--persist", type=str, default="1", help="comma list: 1 persistent launches, 0 one block per tile")
+    ap.add_argument("--scale", type=float, default=1.0, help="epilogue scale (diagnostic builds key experiments on it)")
     ap.add_argument("--cold", action="store_true", help="rotate over 12 weight copies so weights come from HBM")
     args = ap.parse_args()
     from ccnet_amd import lib as _lib
@@ -96,26 +97,26 @@ def main():
         rs = []
         _lib.load().ccnet_set_option(0, -1)
         _lib.load().ccnet_set_option(4, 0)
-        ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act).t.clone()
+        ref_out = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act, scale=args.scale).t.clone()
         for cfg, pers in cfgs:
             _lib.load().ccnet_set_option(0, cfg)
             _lib.load().ccnet_set_option(4, pers)
             try:
                 for _ in range(6):
-                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act)
+                    o = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act, scale=args.scale)
             except Exception as e:  # report and keep sweeping
                 print(f"cfg {cfg} failed: {e}", flush=True)
                 rs.append((0.0, 1e9))
                 continue
             torch.cuda.synchronize()
-            o_chk = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act).t
+            o_chk = ops.conv(x1, w, b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act, scale=args.scale).t
             if not torch.equal(o_chk, ref_out):
                 print(f"  !! cfg {cfg} differs from the heuristic config: max abs "
                       f"{(o_chk.float() - ref_out.float()).abs().max().item():.3e}", flush=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for it in range(args.iters):
-                o = ops.conv(x1, ws[it % ncopy], b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act)
+                o = ops.conv(x1, ws[it % ncopy], b, Cout, R=R, stride=stride, ups=ups, x2=x2, res1=res, act=act, scale=args.scale)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
