@@ -609,12 +609,15 @@ int pick_cfg(int M, int Cout, int K, int batch, bool geglu, bool has_res) {
 
 }  // namespace
 
+extern int g_gn_onepass;  // norm.hip
+
 extern "C" int ccnet_set_option(int key, int value) {
     if (key == 0) { g_force_cfg = value; return CCNET_OK; }  // force conv tile configuration (-1 = heuristic)
     if (key == 1) { g_dbg_zero = value; return CCNET_OK; }
     if (key == 2) { g_order = value; return CCNET_OK; }
     if (key == 3) { g_force_splitk = value; return CCNET_OK; }
     if (key == 4) { g_persist = value; return CCNET_OK; }
+    if (key == 6) { g_gn_onepass = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 

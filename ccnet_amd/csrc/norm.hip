@@ -231,6 +231,99 @@ extern "C" size_t ccnet_groupnorm_workspace_bytes(int N, int HW, int C, int grou
     return (size_t)N * chunks * groups * 2 * sizeof(float);
 }
 
+// One-pass GroupNorm for the deeper levels: one block per (image, group) keeps its whole slice (HW pixels x cpg
+// channels, <= GN1_MAXV 16-B vectors per thread) in registers -- one read and one write of the tensor (4 B/element)
+// and one launch instead of the 6 B/element and two launches of the stats + apply pair.  Needs cpg % 8 == 0 (the
+// slice of a pixel is whole 16-B vectors) and the block size a multiple of the vectors per pixel, so a thread always
+// holds the same 8 channels (its gamma / beta live in registers).  The 32 groups of an image share every 128-B line
+// of it, so consecutive blocks of an XCD (blockIdx % 8) walk the groups of ONE image: the lines come from HBM once
+// per XCD.  Statistics are the two-pass mean / centred M2 over the registers, reduced in a fixed order.
+constexpr int GN1_MAXV = 10;
+
+__global__ __launch_bounds__(1024) void gn_onepass_kernel(const GnArgs a, int vpp) {
+    __shared__ float s_red[32];
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    // XCD-aware (image, group) assignment: XCD x takes the images n with n % 8 == x, group-fastest
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int n, g;
+    if ((gridDim.x & 7) == 0 && (a.N & 7) == 0) {
+        n = (j / a.groups) * 8 + xcd; g = j % a.groups;
+    } else {
+        n = blockIdx.x / a.groups; g = blockIdx.x % a.groups;
+    }
+    (void)per_xcd;
+    const int c0 = g * a.cpg;
+    const __bf16* src; int ld;
+    if (c0 < a.C1) { src = a.x1 + (long long)n * a.HW * a.ldx1 + c0; ld = a.ldx1; }
+    else { src = a.x2 + (long long)n * a.HW * a.ldx2 + (c0 - a.C1); ld = a.ldx2; }
+    const int nvec = a.HW * vpp;
+    const int jv = tid % vpp;  // this thread's 8-channel column inside the group (T % vpp == 0)
+    const int p0 = tid / vpp, pstep = T / vpp;  // vector k of this thread belongs to pixel p0 + k * pstep
+    u32x4 v[GN1_MAXV];
+#pragma unroll
+    for (int k = 0; k < GN1_MAXV; ++k) {
+        const int idx = tid + k * T;
+        v[k] = idx < nvec ? *(const u32x4*)(src + (long long)(p0 + k * pstep) * ld + jv * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    auto block_sum = [&](float x) {
+        x = wave_sum(x);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = x;
+        __syncthreads();
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += s_red[w];  // fixed order
+        return t;
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN1_MAXV; ++k) {
+        float f[8];
+        unpack8(v[k], f);  // (vectors beyond nvec are zeros)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+    }
+    const float cnt = (float)a.HW * (float)a.cpg;
+    const float mean = block_sum(s) / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN1_MAXV; ++k) {
+        if (tid + k * T < nvec) {
+            float f[8];
+            unpack8(v[k], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; m2 += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(m2) / cnt + a.eps);
+    float ga[8], be[8];
+    {
+        const f32x4 g0 = *(const f32x4*)(a.gamma + c0 + jv * 8), g1 = *(const f32x4*)(a.gamma + c0 + jv * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(a.beta + c0 + jv * 8), b1 = *(const f32x4*)(a.beta + c0 + jv * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ga[e] = g0[e] * rstd; ga[4 + e] = g1[e] * rstd;
+            be[e] = b0[e] - mean * ga[e]; be[4 + e] = b1[e] - mean * ga[4 + e];
+        }
+    }
+    __bf16* dst = a.out + (long long)n * a.HW * a.ldo + c0 + jv * 8;
+#pragma unroll
+    for (int k = 0; k < GN1_MAXV; ++k) {
+        const int idx = tid + k * T;
+        if (idx < nvec) {
+            float f[8];
+            unpack8(v[k], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[e] = fmaf(f[e], ga[e], be[e]);
+                if (a.silu) f[e] = silu_f(f[e]);
+            }
+            *(u32x4*)(dst + (long long)(p0 + k * pstep) * a.ldo) = pack8(f);
+        }
+    }
+}
+
+int g_gn_onepass = 1;  // tuning (ccnet_set_option key 6): 0 = always the two-kernel path
+
 extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2, int N,
                                     int HW, int groups, float eps, const float* gamma, const float* beta,
                                     int silu, void* out, int ldo, void* workspace, size_t workspace_bytes,
@@ -248,6 +341,19 @@ extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void
     gn_plan(N, HW, C, a.chunks, a.ppc);
     if (workspace_bytes < (size_t)N * a.chunks * groups * 2 * sizeof(float)) return CCNET_EWS;
     hipStream_t st = (hipStream_t)stream;
+    if (g_gn_onepass && (a.cpg % 8) == 0 && (C1 % a.cpg) == 0) {
+        const int vpp = a.cpg / 8;
+        int unit = vpp;  // block size: a multiple of 64 and of vpp
+        while (unit % 64) unit += vpp;
+        const long long nvec = (long long)HW * vpp;
+        int T = unit;
+        while (T + unit <= 1024 && (long long)T * GN1_MAXV < nvec) T += unit;
+        if (unit <= 1024 && (long long)T * GN1_MAXV >= nvec && (long long)N * groups <= 0x7fffffffLL) {
+            hipLaunchKernelGGL(gn_onepass_kernel, dim3(N * groups), dim3(T), 0, st, a, vpp);
+            CCNET_LAUNCH_CHECK();
+            return CCNET_OK;
+        }
+    }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, N), dim3(GN_THREADS), 0, st, a);
     CCNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_apply_kernel, dim3(a.chunks, N), dim3(GN_THREADS), 0, st, a);

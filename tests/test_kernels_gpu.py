@@ -142,7 +142,9 @@ def test_gemm_batched(cuda):
 
 
 GN_CASES = [(2, 16, 16, 320, 0), (2, 8, 8, 1280, 1280), (1, 7, 7, 256, 0), (2, 32, 32, 128, 0), (3, 4, 4, 640, 320),
-            (2, 64, 64, 320, 0)]
+            (2, 64, 64, 320, 0),
+            # one-pass kernel (channels per group % 8 == 0): XCD-grouped images, two sources, several vectors per thread
+            (8, 16, 16, 1280, 0), (16, 32, 32, 640, 640), (2, 16, 16, 2560, 0), (9, 8, 8, 1280, 0), (8, 32, 32, 1280, 640)]
 
 
 @pytest.mark.parametrize("case", GN_CASES)
@@ -163,6 +165,26 @@ def test_groupnorm(cuda, case, silu):
     if silu:
         ref = F.silu(ref)
     _close(_nchw(out), ref, atol=1e-2, what=f"groupnorm {case}")
+
+
+def test_groupnorm_one_pass_agrees_with_two_kernel_path(cuda):
+    from ccnet_amd import lib as _lib
+    ops = _ops()
+    l = _lib.load()
+    x1 = _rand_act(8, 16, 16, 640, cuda, 24, scale=3.0)
+    x2 = _rand_act(8, 16, 16, 640, cuda, 25)
+    g = torch.Generator().manual_seed(26)
+    gamma, beta = (1 + 0.2 * torch.randn(1280, generator=g)).to(cuda), (0.2 * torch.randn(1280, generator=g)).to(cuda)
+    try:
+        l.ccnet_set_option(6, 0)
+        two = ops.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2).t.clone()
+        l.ccnet_set_option(6, 1)
+        one = ops.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2).t
+        again = ops.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2).t
+    finally:
+        l.ccnet_set_option(6, 1)
+    assert torch.equal(one, again)                      # deterministic
+    assert (one.float() - two.float()).abs().max().item() <= 4e-2  # bf16 outputs of two summation orders: <= 1-2 ulp
 
 
 @pytest.mark.parametrize("rows,C", [(100, 320), (64, 640), (33, 1280), (10, 512), (7, 768)])
