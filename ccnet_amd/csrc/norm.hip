@@ -238,32 +238,35 @@ extern "C" size_t ccnet_groupnorm_workspace_bytes(int N, int HW, int C, int grou
 // holds the same 8 channels (its gamma / beta live in registers).  The 32 groups of an image share every 128-B line
 // of it, so consecutive blocks of an XCD (blockIdx % 8) walk the groups of ONE image: the lines come from HBM once
 // per XCD.  Statistics are the two-pass mean / centred M2 over the registers, reduced in a fixed order.
-constexpr int GN1_MAXV = 10;
-
+// VW = dwords per vector (4 / 2 / 1: channels per group a multiple of 8 / 4 / 2), MAXV vectors per thread.
+template <int VW, int MAXV>
 __global__ __launch_bounds__(1024) void gn_onepass_kernel(const GnArgs a, int vpp) {
+    constexpr int CH = 2 * VW;  // channels per vector
     __shared__ float s_red[32];
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     // XCD-aware (image, group) assignment: XCD x takes the images n with n % 8 == x, group-fastest
-    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     int n, g;
     if ((gridDim.x & 7) == 0 && (a.N & 7) == 0) {
         n = (j / a.groups) * 8 + xcd; g = j % a.groups;
     } else {
         n = blockIdx.x / a.groups; g = blockIdx.x % a.groups;
     }
-    (void)per_xcd;
     const int c0 = g * a.cpg;
     const __bf16* src; int ld;
     if (c0 < a.C1) { src = a.x1 + (long long)n * a.HW * a.ldx1 + c0; ld = a.ldx1; }
     else { src = a.x2 + (long long)n * a.HW * a.ldx2 + (c0 - a.C1); ld = a.ldx2; }
     const int nvec = a.HW * vpp;
-    const int jv = tid % vpp;  // this thread's 8-channel column inside the group (T % vpp == 0)
+    const int jv = tid % vpp;  // this thread's channel column inside the group (T % vpp == 0)
     const int p0 = tid / vpp, pstep = T / vpp;  // vector k of this thread belongs to pixel p0 + k * pstep
-    u32x4 v[GN1_MAXV];
+    typedef __attribute__((ext_vector_type(VW))) unsigned int vec_t;
+    vec_t v[MAXV];
 #pragma unroll
-    for (int k = 0; k < GN1_MAXV; ++k) {
-        const int idx = tid + k * T;
-        v[k] = idx < nvec ? *(const u32x4*)(src + (long long)(p0 + k * pstep) * ld + jv * 8) : u32x4{0u, 0u, 0u, 0u};
+    for (int k = 0; k < MAXV; ++k) {
+        vec_t z;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) z[e] = 0u;
+        v[k] = tid + k * T < nvec ? *(const vec_t*)(src + (long long)(p0 + k * pstep) * ld + jv * CH) : z;
     }
     auto block_sum = [&](float x) {
         x = wave_sum(x);
@@ -274,55 +277,64 @@ __global__ __launch_bounds__(1024) void gn_onepass_kernel(const GnArgs a, int vp
         for (int w = 0; w < nw; ++w) t += s_red[w];  // fixed order
         return t;
     };
+    auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+    auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < GN1_MAXV; ++k) {
-        float f[8];
-        unpack8(v[k], f);  // (vectors beyond nvec are zeros)
+    for (int k = 0; k < MAXV; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += f[e];
-    }
+        for (int e = 0; e < VW; ++e) s += lo(v[k][e]) + hi(v[k][e]);  // (vectors beyond nvec are zeros)
     const float cnt = (float)a.HW * (float)a.cpg;
     const float mean = block_sum(s) / cnt;
     float m2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < GN1_MAXV; ++k) {
+    for (int k = 0; k < MAXV; ++k) {
         if (tid + k * T < nvec) {
-            float f[8];
-            unpack8(v[k], f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; m2 += d * d; }
+            for (int e = 0; e < VW; ++e) {
+                const float d0 = lo(v[k][e]) - mean, d1 = hi(v[k][e]) - mean;
+                m2 += d0 * d0 + d1 * d1;
+            }
         }
     }
     const float rstd = rsqrtf(block_sum(m2) / cnt + a.eps);
-    float ga[8], be[8];
-    {
-        const f32x4 g0 = *(const f32x4*)(a.gamma + c0 + jv * 8), g1 = *(const f32x4*)(a.gamma + c0 + jv * 8 + 4);
-        const f32x4 b0 = *(const f32x4*)(a.beta + c0 + jv * 8), b1 = *(const f32x4*)(a.beta + c0 + jv * 8 + 4);
+    float ga[CH], be[CH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ga[e] = g0[e] * rstd; ga[4 + e] = g1[e] * rstd;
-            be[e] = b0[e] - mean * ga[e]; be[4 + e] = b1[e] - mean * ga[4 + e];
-        }
+    for (int e = 0; e < CH; ++e) {
+        ga[e] = a.gamma[c0 + jv * CH + e] * rstd;
+        be[e] = a.beta[c0 + jv * CH + e] - mean * ga[e];
     }
-    __bf16* dst = a.out + (long long)n * a.HW * a.ldo + c0 + jv * 8;
+    __bf16* dst = a.out + (long long)n * a.HW * a.ldo + c0 + jv * CH;
 #pragma unroll
-    for (int k = 0; k < GN1_MAXV; ++k) {
-        const int idx = tid + k * T;
-        if (idx < nvec) {
-            float f[8];
-            unpack8(v[k], f);
+    for (int k = 0; k < MAXV; ++k) {
+        if (tid + k * T < nvec) {
+            vec_t o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f[e] = fmaf(f[e], ga[e], be[e]);
-                if (a.silu) f[e] = silu_f(f[e]);
+            for (int e = 0; e < VW; ++e) {
+                float f0 = fmaf(lo(v[k][e]), ga[2 * e], be[2 * e]), f1 = fmaf(hi(v[k][e]), ga[2 * e + 1], be[2 * e + 1]);
+                if (a.silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
+                o[e] = pack_bf16x2(f0, f1);
             }
-            *(u32x4*)(dst + (long long)(p0 + k * pstep) * a.ldo) = pack8(f);
+            *(vec_t*)(dst + (long long)(p0 + k * pstep) * a.ldo) = o;
         }
     }
 }
 
-int g_gn_onepass = 1;  // tuning (ccnet_set_option key 6): 0 = always the two-kernel path
+template <int VW, int MAXV>
+bool launch_gn_onepass(const GnArgs& a, hipStream_t st) {
+    const int vpp = a.cpg / (2 * VW);
+    int unit = vpp;  // block size: a multiple of 64 and of the vectors per pixel
+    while (unit % 64) unit += vpp;
+    if (unit > 1024) return false;
+    const long long nvec = (long long)a.HW * vpp;
+    int T = unit;
+    while (T + unit <= 1024 && (long long)T * MAXV < nvec) T += unit;
+    if ((long long)T * MAXV < nvec) return false;
+    hipLaunchKernelGGL((gn_onepass_kernel<VW, MAXV>), dim3(a.N * a.groups), dim3(T), 0, st, a, vpp);
+    return true;
+}
+
+int g_gn_onepass = 2;  // tuning (ccnet_set_option key 6): 0 = always the two-kernel path, 1 / 2 / 3 = narrowest vector 16 / 8 / 4 B
 
 extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2, int N,
                                     int HW, int groups, float eps, const float* gamma, const float* beta,
@@ -341,15 +353,14 @@ extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void
     gn_plan(N, HW, C, a.chunks, a.ppc);
     if (workspace_bytes < (size_t)N * a.chunks * groups * 2 * sizeof(float)) return CCNET_EWS;
     hipStream_t st = (hipStream_t)stream;
-    if (g_gn_onepass && (a.cpg % 8) == 0 && (C1 % a.cpg) == 0) {
-        const int vpp = a.cpg / 8;
-        int unit = vpp;  // block size: a multiple of 64 and of vpp
-        while (unit % 64) unit += vpp;
-        const long long nvec = (long long)HW * vpp;
-        int T = unit;
-        while (T + unit <= 1024 && (long long)T * GN1_MAXV < nvec) T += unit;
-        if (unit <= 1024 && (long long)T * GN1_MAXV >= nvec && (long long)N * groups <= 0x7fffffffLL) {
-            hipLaunchKernelGGL(gn_onepass_kernel, dim3(N * groups), dim3(T), 0, st, a, vpp);
+    if (g_gn_onepass && (C1 % a.cpg) == 0 && (long long)N * groups <= 0x7fffffffLL) {
+        // widest vector the group width allows; g_gn_onepass = 1: 16-B vectors only, 2: also 8-B, 3: also 4-B
+        bool done = false;
+        if ((a.cpg % 8) == 0) done = launch_gn_onepass<4, 10>(a, st);
+        else if ((a.cpg % 4) == 0 && g_gn_onepass >= 2 && (long long)HW * a.cpg <= 65536)  // (measured: slower beyond)
+            done = launch_gn_onepass<2, 22>(a, st);
+        else if ((a.cpg % 2) == 0 && g_gn_onepass >= 3) done = launch_gn_onepass<1, 32>(a, st);
+        if (done) {
             CCNET_LAUNCH_CHECK();
             return CCNET_OK;
         }
