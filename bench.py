@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=6)  # ~2 s per step on 16 host cores: a 10-15 s sample
     ap.add_argument("--no-prof", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every launch from the host (rocprofv3 --pmc passes: counter collection crashes on graph replay)")
