@@ -550,10 +550,16 @@ extern "C" int ccnet_conv_in_small(const float* x, int Nsrc, int N, int Cin, int
 #undef CIS_ARGS
 }
 
+extern "C" int ccnet_conv_out_nchw(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, const float* bias,
+                                   int Cout, float* out, void* stream);  // gemm_conv.hip
+
 extern "C" int ccnet_conv_out_small(const void* x, int ldx, int N, int H, int W, int Cin, const void* w,
                                     const float* bias, int Cout, float* out, void* stream) {
     if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8) || (ldx % 8) || Cout <= 0 || Cout > 8)
         return CCNET_EINVAL;
+    // the MFMA route: 64-channel K-steps of the implicit-GEMM kernel, unless a batch exceeds its 2-GiB activation window
+    if ((Cin % 64) == 0 && ((long long)N * H * W - 1) * ldx * 2 + (long long)Cin * 2 < 0x7fffffffLL)
+        return ccnet_conv_out_nchw(x, ldx, N, H, W, Cin, w, bias, Cout, out, stream);
     if (Cin > 512) return CCNET_EUNSUP;  // one 16-B channel chunk per lane
     int G = 1;
     while (G * 8 < Cin) G <<= 1;

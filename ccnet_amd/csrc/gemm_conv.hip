@@ -44,6 +44,7 @@ struct ConvArgs {
     float scale;
     int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
     long long sx1, sw, so;
+    float* out32; int cout_real;  // SPLIT instances only: != nullptr -> final fp32 NCHW output (+ bias), Cout <= 8 edge convs
     int splitk;   // > 1: blockIdx.y selects a K slice, raw fp32 partial sums go to ws[slice][M][Cout]
     float* ws;
     unsigned x1_bytes, x2_bytes, w_bytes;
@@ -310,6 +311,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     if constexpr (SPLIT) {
         // raw fp32 partial sums, 16 B per lane (4 consecutive couts of its pixel); ccnet's reduce kernel sums the
         // slices in slice order and applies the epilogue, so results do not depend on the launch geometry
+        if (a.out32) {
+            // edge convolution with a handful of couts (UNet / AEKL output conv): fp32 NCHW, bias added here; lanes of a
+            // store are consecutive pixels of one cout plane
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
+                if (m < a.M) {
+                    const int img = m / a.HWout, pix = m - img * a.HWout;
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int co = cn0 + wn * 32 * TI + i * 32 + 8 * q + 4 * hh + e;
+                                if (co < a.cout_real)
+                                    a.out32[((long long)img * a.cout_real + co) * a.HWout + pix] =
+                                        acc[i][j][4 * q + e] + (a.bias ? a.bias[co] : 0.f);
+                            }
+                }
+            }
+            STAMP(4);
+            return;
+        }
         float* wsl = a.ws + (long long)slice * a.M * a.Cout;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -542,7 +567,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST>), dim3(grid, SPLIT ? b.splitk : 1, batch),
                        dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
-    if (SPLIT) {
+    if (SPLIT && !b.out32) {
         const long long items = (long long)b.M * (b.Cout / 8);
         const int grid = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, b);
@@ -577,6 +602,8 @@ const TileCfg kCfgs[] = {
     {128, 128, launch<2, 2, 2, 2, false, 3, 32>, nullptr, nullptr},              // 28: 48 KB: three blocks per CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+// 256 pixels x 32 couts, 4 waves, two blocks per CU: the output convolutions (Cout <= 8); raw-accumulator epilogue
+const LaunchFn kEdgeOutFn = launch<4, 1, 2, 1, false, 3, 64, true>;
 
 int pick_cfg(int M, int Cout, int K, int batch, bool geglu, bool has_res) {
     if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (geglu ? kCfgs[g_force_cfg].fn_geglu : kCfgs[g_force_cfg].fn))
@@ -699,6 +726,25 @@ int plan_splitk(const ccnet_conv_params* p, int M, int KT, int batch, int* cfg) 
     return S;
 }
 }  // namespace
+
+// Output convolution (3x3, stride 1, pad 1, Cin % 64 == 0, Cout <= 8) on the implicit-GEMM kernel: NHWC bf16 in, fp32 NCHW
+// out.  Called by ccnet_conv_out_small (elementwise.hip); w is [Cout][9][Cin] bf16 -- the rows a 32-cout tile reads
+// beyond Cout fall outside the weight descriptor and come back as zeros.
+extern "C" int ccnet_conv_out_nchw(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, const float* bias,
+                                   int Cout, float* out, void* stream) {
+    if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) || (ldx % 8) || Cout <= 0 || Cout > 8)
+        return CCNET_EINVAL;
+    ConvArgs a{};
+    a.x1 = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = bias;
+    a.N = N; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W; a.C1 = Cin; a.C2 = 0; a.Cout = Cout; a.R = 3; a.stride = 1;
+    a.pad = 1; a.ups = 1; a.ldx1 = ldx; a.ldw = 9 * Cin; a.act = 0; a.scale = 1.0f;
+    a.M = N * H * W; a.HWout = H * W; a.splitk = 1; a.out32 = out; a.cout_real = Cout;
+    const long long xb1 = ((long long)N * H * W - 1) * ldx * 2 + (long long)Cin * 2;
+    const long long wb = (long long)Cout * 9 * Cin * 2;
+    if (xb1 >= 0x7fffffffLL) return CCNET_EUNSUP;
+    a.x1_bytes = (unsigned)xb1; a.w_bytes = (unsigned)wb;
+    return kEdgeOutFn(a, 1, (hipStream_t)stream);
+}
 
 extern "C" size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p) {
     if (!p || p->C1 <= 0 || p->Cout <= 0 || p->N <= 0) return 0;

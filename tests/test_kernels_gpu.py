@@ -327,7 +327,8 @@ def test_small_convs(cuda):
     yref = F.conv2d(_nchw(xa), wop.float().reshape(4, 3, 3, 320).permute(0, 3, 1, 2), bo.to(cuda), padding=1)
     assert (y - yref).abs().max() < 2e-3
     # AEKL-style output convs: few input channels (several pixel strips per wave), ragged width, 1 / 3 / 8 couts
-    for (Cin, Cout, H, W, N) in [(128, 1, 24, 20, 3), (64, 3, 9, 13, 2), (512, 8, 5, 8, 1), (192, 2, 7, 31, 2)]:
+    for (Cin, Cout, H, W, N) in [(128, 1, 24, 20, 3), (64, 3, 9, 13, 2), (512, 8, 5, 8, 1), (192, 2, 7, 31, 2),
+                                 (72, 2, 6, 9, 1), (320, 4, 16, 70, 1), (128, 5, 3, 97, 2)]:
         xa = _rand_act(N, H, W, Cin, cuda, 74 + Cin)
         wo = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
         bo = torch.randn(Cout, generator=g)
