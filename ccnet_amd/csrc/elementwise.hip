@@ -173,69 +173,93 @@ __global__ __launch_bounds__(64) void linear_f32_mfma_kernel(const float* x, int
 }
 
 // ------------------------------------------------------------------ edge convolutions
-// conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16; thread = (pixel, 8 couts); blockIdx.y = chunk of <= 256 couts
-// whose weights sit in LDS k-major ([tap][cout]) so the 8 weights a lane needs per tap are two ds_read_b128 and
-// consecutive lanes (consecutive cout groups) hit consecutive banks.
-constexpr int CIS_CHUNK = 256;
+// conv_in_small: fp32 NCHW (Cin <= 8) -> NHWC bf16 on the fp32-input matrix core (v_mfma_f32_32x32x2_f32: an exact
+// fp32 fma chain, so the latent / conditioning image are not rounded to bf16 on the way in).  A wave owns 32 consecutive
+// output pixels of a row: its im2col column (K = 9 Cin values per pixel, two per MFMA step, one per lane half) is gathered
+// once into registers and reused for every 32-cout block; the weights sit in LDS k-major ([k][cout], consecutive lanes =
+// consecutive couts = consecutive banks) with the bias as an extra row the accumulators start from.  The epilogue is the
+// implicit-GEMM kernel's: v_permlane32_swap pairs -> 8 consecutive couts per lane -> one 16-B store (and residual load).
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_small_kernel(const float* x, int Nsrc, int N, int H, int W,
                                                             const float* w, const float* bias, int Cout, int stride,
                                                             int act, const __bf16* res, int Nres, int ldres,
                                                             __bf16* out, int ldo, int Hout, int Wout) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];  // [K][CIS_CHUNK] + bias[CIS_CHUNK]
-    constexpr int K = CIN * 9;
-    const int c_base = blockIdx.y * CIS_CHUNK;
-    const int c_cnt = min(CIS_CHUNK, ldo - c_base);            // channels of the padded row this block writes
-    const int c_real = max(0, min(c_cnt, Cout - c_base));      // of which real output channels
-    for (int i = threadIdx.x; i < (K + 1) * CIS_CHUNK; i += 256) {
-        const int k = i / CIS_CHUNK, c = i % CIS_CHUNK;
-        float v = 0.f;
-        if (c < c_real) v = k < K ? w[(long long)(c_base + c) * K + k] : (bias ? bias[c_base + c] : 0.f);
-        sw[i] = v;
-    }
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [2 * STEPS + 1][CP]
+    constexpr int K = CIN * 9, STEPS = (K + 1) / 2;
+    const int nb = (ldo + 31) / 32, CP = nb * 32 + 4;  // (+4: the k-major scatter below spreads over the banks)
+    for (int i = threadIdx.x; i < (2 * STEPS + 1) * CP; i += 256) sw[i] = 0.f;
     __syncthreads();
-    const int cg = c_cnt / 8;
-    const long long total = (long long)N * Hout * Wout * cg;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int g = (int)(idx % cg);
-        const long long pixel = idx / cg;
-        const int ox = (int)(pixel % Wout), oy = (int)((pixel / Wout) % Hout), n = (int)(pixel / ((long long)Wout * Hout));
+    for (int i = threadIdx.x; i < Cout * K; i += 256) {  // coalesced read of [Cout][K], transposed into LDS
+        const int c = i / K, k = i - c * K;
+        sw[k * CP + c] = w[i];
+    }
+    if (bias)
+        for (int c = threadIdx.x; c < Cout; c += 256) sw[2 * STEPS * CP + c] = bias[c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+    auto swap32 = [](float& lo, float& hi) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+    };
+    const int spr = (Wout + 31) / 32;
+    const long long nstrips = (long long)N * Hout * spr;
+    for (long long st = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); st < nstrips; st += (long long)gridDim.x * 4) {
+        const int sx = (int)(st % spr), oy = (int)((st / spr) % Hout), n = (int)(st / ((long long)spr * Hout));
+        const int ox = sx * 32 + l31;
+        const bool pok = ox < Wout;
         const float* xb = x + (long long)(n % Nsrc) * CIN * H * W;
-        float v[8];
-        {
-            const f32x4 b0 = *(const f32x4*)(sw + K * CIS_CHUNK + g * 8), b1 = *(const f32x4*)(sw + K * CIS_CHUNK + g * 8 + 4);
+        float xv[STEPS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = b0[e]; v[4 + e] = b1[e]; }
+        for (int s = 0; s < STEPS; ++s) {
+            // k = 2 s + hh -> (channel, kr, ks); both candidates are compile-time, the lane half selects
+            constexpr int dummy = 0; (void)dummy;
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int c = hh ? k1 / 9 : k0 / 9, kr = hh ? (k1 % 9) / 3 : (k0 % 9) / 3, ks = hh ? k1 % 3 : k0 % 3;
+            const int iy = oy * stride - 1 + kr, ix = ox * stride - 1 + ks;
+            const bool ok = pok && (hh ? k1 < K : true) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            xv[s] = ok ? xb[((long long)c * H + iy) * W + ix] : 0.f;
         }
-        // one input channel (9 taps, 18 ds_read_b128) per trip: fully unrolled over CIN the weight fragments alone
-        // exceed the register file and hipcc spills
-#pragma unroll 1
-        for (int c = 0; c < CIN; ++c)
+        const long long pixel = ((long long)n * Hout + oy) * Wout + ox;
+        __bf16* orow = out + pixel * ldo;
+        const __bf16* rrow = res ? res + (((long long)(n % Nres) * Hout + oy) * Wout + ox) * ldres : nullptr;
+        for (int cb = 0; cb < nb; ++cb) {
+            const float* wcol = sw + cb * 32 + l31;
+            f32x16 acc;
 #pragma unroll
-            for (int kr = 0; kr < 3; ++kr)
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *(const f32x4*)(sw + 2 * STEPS * CP + cb * 32 + 8 * q + 4 * hh);
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const int iy = oy * stride - 1 + kr, ix = ox * stride - 1 + ks;
-                    const float xv = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                                         ? xb[((long long)c * H + iy) * W + ix] : 0.f;
-                    const float* wr = sw + (c * 9 + kr * 3 + ks) * CIS_CHUNK + g * 8;
-                    const f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+                for (int e = 0; e < 4; ++e) acc[4 * q + e] = b4[e];
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += w0[e] * xv; v[4 + e] += w1[e] * xv; }
+            for (int s = 0; s < STEPS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[(2 * s + hh) * CP], xv[s], acc, 0, 0, 0);
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = silu_f(acc[e]);  // silu(0) = 0 keeps the padded channels zero
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo = acc[8 * p + e], hi = acc[8 * p + 4 + e];
+                    swap32(lo, hi);
+                    v[e] = lo; v[4 + e] = hi;
                 }
-        if (act == 1) {
+                const int col = cb * 32 + 16 * p + 8 * hh;  // this lane's 8 consecutive couts
+                if (pok && col < ldo) {
+                    if (rrow && col < Cout) {
+                        float r[8];
+                        unpack8(*(const u32x4*)(rrow + col), r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);  // silu(0) = 0 keeps the padded channels zero
+                        for (int e = 0; e < 8; ++e)
+                            if (col + e < Cout) v[e] += r[e];
+                    }
+                    *(u32x4*)(orow + col) = pack8(v);
+                }
+            }
         }
-        if (res && g * 8 < c_real) {
-            float r[8];
-            const long long rpix = ((long long)(n % Nres) * Hout + oy) * Wout + ox;
-            unpack8(*(const u32x4*)(res + rpix * ldres + c_base + g * 8), r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (g * 8 + e < c_real) v[e] += r[e];
-        }
-        *(u32x4*)(out + pixel * ldo + c_base + g * 8) = pack8(v);
     }
 }
 
@@ -243,19 +267,21 @@ template <int CIN>
 int launch_conv_in_small(const float* x, int Nsrc, int N, int H, int W, const float* w, const float* bias, int Cout,
                          int stride, int act, const void* res, int Nres, int ldres, void* out, int ldo, int Hout,
                          int Wout, hipStream_t st) {
-    const size_t lds = (size_t)(CIN * 9 + 1) * CIS_CHUNK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    constexpr int STEPS = (CIN * 9 + 1) / 2;
+    const int CP = (ldo + 31) / 32 * 32 + 4;
+    const size_t lds = (size_t)(2 * STEPS + 1) * CP * sizeof(float);
+    if (lds > 150 * 1024) return CCNET_EUNSUP;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         if (hipFuncSetAttribute((const void*)conv_in_small_kernel<CIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return CCNET_ELAUNCH;
-        attr_set = true;
+        attr_lds = lds;
     }
-    const int ychunks = (ldo + CIS_CHUNK - 1) / CIS_CHUNK;
-    const long long total = (long long)N * Hout * Wout * ((ldo < CIS_CHUNK ? ldo : CIS_CHUNK) / 8);
-    long long g = (total + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(conv_in_small_kernel<CIN>, dim3((int)g, ychunks), dim3(256), lds, st, x, Nsrc, N, H, W, w, bias,
+    const long long waves = (long long)N * Hout * ((Wout + 31) / 32);
+    long long g = (waves + 3) / 4;
+    if (g > 768) g = 768;  // three resident blocks per CU walk the strips: the weight image is filled 768 times, not per strip
+    hipLaunchKernelGGL(conv_in_small_kernel<CIN>, dim3((int)g), dim3(256), lds, st, x, Nsrc, N, H, W, w, bias,
                        Cout, stride, act, (const __bf16*)res, Nres, ldres, (__bf16*)out, ldo, Hout, Wout);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;

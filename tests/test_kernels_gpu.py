@@ -318,6 +318,17 @@ def test_small_convs(cuda):
     o1 = ops.conv_in_small(c, 2, w1.to(cuda), b1.to(cuda), 16, 64, act=1)
     _close(_nchw(o1, 16), F.silu(F.conv2d(c, w1.to(cuda), b1.to(cuda), padding=1)), atol=1e-2, what="cond conv_in")
     assert o1.t[:, 16:].abs().max().item() == 0.0
+    # ragged width (not a multiple of the 32-pixel strip), 3 / 8 input channels, stride 2, padded couts, image reuse n % Nsrc
+    for (Cin, Cout, ldo, H, W, stride, N) in [(3, 40, 64, 10, 37, 1, 2), (8, 96, 128, 9, 70, 2, 3), (2, 64, 64, 5, 33, 2, 4)]:
+        xs = torch.randn(2, Cin, H, W, generator=g).to(cuda)
+        ws = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(cuda)
+        bs = torch.randn(Cout, generator=g).to(cuda)
+        o = ops.conv_in_small(xs, N, ws, bs, Cout, ldo, stride=stride, act=1)
+        refx = torch.cat([xs, xs])[:N] if N <= 4 else None
+        ref = F.silu(F.conv2d(torch.cat([xs, xs, xs])[:N] if N == 3 else refx, ws, bs, stride=stride, padding=1))
+        assert (o.H, o.W) == (ref.shape[2], ref.shape[3])
+        _close(_nchw(o, Cout), ref, atol=1e-2, what=f"conv_in_small {Cin}->{Cout} stride {stride}")
+        assert o.t[:, Cout:].abs().max().item() == 0.0 if ldo > Cout else True
     # conv_out: 320 -> 4 to fp32 NCHW
     xa = _rand_act(2, 16, 16, 320, cuda, 73)
     wo = (torch.randn(4, 320, 3, 3, generator=g) / math.sqrt(2880))
