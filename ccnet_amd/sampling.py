@@ -169,7 +169,9 @@ class Sampler:
         self._static_step(g)  # eager once: weight packing, kernel attributes and allocator warm-up stay out of the graph
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: HIP calls of other threads (the RCCL watchdog of a multi-GPU run polls events) must not
+        # invalidate this thread's capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._static_step(g)
         g["graph"] = graph
         self._graphs[key] = g
