@@ -101,8 +101,9 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
     issue_loads(0);
     store_stage(0);
     __syncthreads();
-    auto tile_body = [&](int t, auto tail_c) {
+    auto tile_body = [&](int t, auto tail_c, auto nb_c) {
         constexpr bool tail = decltype(tail_c)::value;
+        constexpr int NB = decltype(nb_c)::value;  // 32-key blocks of this tile that hold keys (1 only in a ragged tail)
         const bool more = t + 1 < ntiles;
         if (more) issue_loads(t + 1);
         const char* kb = smem + (t & 1) * 2 * TILE_BYTES;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         // S^T for the two 32-key blocks
         f32x16 s[2];
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
+        for (int kbk = 0; kbk < NB; ++kbk) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kbk][e] = 0.f;
 #pragma unroll
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         const int kbase = t * KV_TILE + 4 * hh;
         if constexpr (tail) {
 #pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
+            for (int kbk = 0; kbk < NB; ++kbk)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kbase + kbk * 32 + (e & 3) + 8 * (e >> 2);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         }
         float mx = -INFINITY;  // raw-score maximum of this lane's 32 keys, then of the whole row
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
+        for (int kbk = 0; kbk < NB; ++kbk)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kbk][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         float rs = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
+        for (int kbk = 0; kbk < NB; ++kbk)
 #pragma unroll
             for (int sI = 0; sI < 2; ++sI) {
                 float p[8];
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
+            for (int kbk = 0; kbk < NB; ++kbk)
 #pragma unroll
                 for (int sI = 0; sI < 2; ++sI) {
                     const int key0 = kbk * 32 + 16 * sI + 4 * hh;  // first 4 keys; second 4 are +8
@@ -189,9 +190,13 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
     };
     // only the last tile can hold keys beyond Skv: the masking code exists in that instance alone
     const bool ragged = (a.Skv % KV_TILE) != 0;
-    for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::false_type{});
-    if (ragged) tile_body(ntiles - 1, std::true_type{});
-    else tile_body(ntiles - 1, std::false_type{});
+    using two = std::integral_constant<int, 2>;
+    using one = std::integral_constant<int, 1>;
+    for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::false_type{}, two{});
+    // a tail of <= 32 keys (77 prompt tokens = 64 + 13) skips its empty second block: scores, softmax and P.V alike
+    if (ragged && a.Skv - (ntiles - 1) * KV_TILE <= 32) tile_body(ntiles - 1, std::true_type{}, one{});
+    else if (ragged) tile_body(ntiles - 1, std::true_type{}, two{});
+    else tile_body(ntiles - 1, std::false_type{}, two{});
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
