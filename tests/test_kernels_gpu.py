@@ -462,3 +462,57 @@ def test_persistent_tile_loop_matches_one_tile_per_block(cuda, rows, C, geglu):
         l.ccnet_set_option(4, 1)
     if not geglu:  # and against torch
         _close(out.float(), F.linear(x.float(), w.float(), b), atol=3e-2, what="persistent linear")
+
+
+def test_conv_dispatch_sweep(cuda):
+    """Seeded sweep over shapes that land on every branch of the tile / split-K dispatch (small and ragged M, couts that
+    are multiples of 8 / 128 / 256 / 320, short and deep K, residual / rowvec / GEGLU / scale variants) against F.conv2d."""
+    import random
+    ops = _ops()
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(1235)
+    shapes = []
+    for _ in range(28):
+        R = rnd.choice([1, 1, 3])
+        C1 = 64 * rnd.choice([1, 2, 5, 10, 20])
+        C2 = 64 * rnd.choice([0, 0, 0, 1, 5])
+        Cout = rnd.choice([8, 40, 64, 128, 256, 320, 512, 640, 960, 1280, 2560])
+        H = rnd.choice([3, 8, 13, 16, 32])
+        N = rnd.choice([1, 2, 5, 8, 32])
+        if N * H * H * (C1 + C2 + Cout) > 6e7 or R * R * (C1 + C2) * Cout > 3e7:
+            N, H = min(N, 2), min(H, 16)
+        mode = rnd.choice(["plain", "plain", "res", "rowvec", "scale", "geglu"])
+        shapes.append((N, H, C1, C2, Cout, R, mode))
+    shapes += [(32, 8, 1280, 0, 1280, 3, "res"), (32, 8, 2560, 0, 1280, 1, "plain"), (8, 32, 640, 0, 1280, 1, "res"),
+               (2, 64, 320, 0, 2560, 1, "geglu"), (32, 16, 1280, 0, 1280, 1, "res"), (32, 16, 1280, 0, 3840, 1, "plain")]
+    for (N, H, C1, C2, Cout, R, mode) in shapes:
+        x1 = _rand_act(N, H, H, C1, cuda, 11)
+        x2 = _rand_act(N, H, H, C2, cuda, 12) if C2 else None
+        Cin = C1 + C2
+        if mode == "geglu":
+            if Cout % 64 or R != 1:
+                mode = "plain"
+        w = (torch.randn(Cout, Cin * R * R, generator=g) / math.sqrt(Cin * R * R)).to(torch.bfloat16).to(cuda)
+        b = torch.randn(Cout, generator=g).to(cuda)
+        xin = _nchw(x1) if x2 is None else torch.cat([_nchw(x1), _nchw(x2)], 1)
+        ref = F.conv2d(xin, w.float().reshape(Cout, R, R, Cin).permute(0, 3, 1, 2), b, padding=R // 2)
+        what = f"sweep N={N} H={H} C1={C1} C2={C2} Cout={Cout} R={R} {mode}"
+        if mode == "plain":
+            out = ops.conv(x1, w, b, Cout, R=R, x2=x2)
+        elif mode == "res":
+            r1 = _rand_act(N, H, H, Cout, cuda, 13)
+            out = ops.conv(x1, w, b, Cout, R=R, x2=x2, res1=r1)
+            ref = ref + _nchw(r1)
+        elif mode == "rowvec":
+            rv = torch.randn(N, Cout, generator=g).to(cuda)
+            out = ops.conv(x1, w, b, Cout, R=R, x2=x2, rowvec=rv, act=1)
+            ref = F.silu(ref + rv[:, :, None, None])
+        elif mode == "scale":
+            out = ops.conv(x1, w, b, Cout, R=R, x2=x2, scale=0.37)
+            ref = ref * 0.37
+        else:
+            out = ops.conv(x1, ops.geglu_interleave(w), ops.geglu_interleave(b), Cout, R=R, x2=x2, act=2)
+            a, gate = ref.chunk(2, dim=1)
+            ref = a * F.gelu(gate)
+            assert out.C == Cout // 2
+        _close(_nchw(out, ref.shape[1]), ref, atol=3e-2, what=what)
