@@ -605,33 +605,67 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // 256 pixels x 32 couts, 4 waves, two blocks per CU: the output convolutions (Cout <= 8); raw-accumulator epilogue
 const LaunchFn kEdgeOutFn = launch<4, 1, 2, 1, false, 3, 64, true>;
 
-int pick_cfg(int M, int Cout, int K, int batch, bool geglu, bool has_res) {
-    if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (geglu ? kCfgs[g_force_cfg].fn_geglu : kCfgs[g_force_cfg].fn))
-        return g_force_cfg;
-    auto blocks = [&](int c) {
-        return (long long)((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((Cout + kCfgs[c].bn - 1) / kCfgs[c].bn) * batch;
-    };
-    // Measured on MI355X at CFG batch 32 with HBM-cold weights (tools/bench_conv.py --cold).  The L2 -> LDS path
-    // delivers ~64 B/clk/CU, so a tile's DMA time per K-step, (BM+BN)*128 B / 64, must stay well under its MFMA time
-    // BM*BN/32 clk: the 8-wave 256x320 / 256x256 tiles (45-50 % DMA duty) beat 128x128 (100 %) wherever the layer
-    // still yields >= ~200 tiles; smaller-M layers trade tile size for tile count.
+// Dispatch = a few rules for the big layers (tuned in situ at CFG batch 32) + a cost model for everything else.
+//
+// The model prices a (tile configuration, split-K factor S) pair as
+//     rounds * (a + b * KT / S)  [+ r0 + r1 * M * Cout * S for the reduce pass when S > 1],   rounds = ceil(tiles * S / resident blocks)
+// with a (start-up + epilogue of one tile) and b (one 64-deep K step) fitted per configuration by tools/fit_dispatch.py to
+// tools/sweep_small.sh timings of every UNet layer shape at 1, 2, 4, 8 and 16 images (cold weights; rms error 9 %; its pick is
+// within 1 % of the best measured pair summed over the layers at each size).  Rounds are what the old tile-count thresholds
+// approximated: a tile count just over a multiple of 256 costs a whole extra round.
+struct CostRow { int cfg; float a_us, b_us; int per_cu; };
+const CostRow kCost[] = {{19, 4.94f, 0.5370f, 1}, {15, 7.85f, 0.7451f, 1}, {0, 6.48f, 0.9108f, 2},
+                         {3, 8.93f, 1.3780f, 1},  {20, 11.80f, 1.4901f, 1}, {23, 13.00f, 1.7703f, 1}};
+constexpr float kReduceUs = 3.14f, kReduceUsPerElem = 1.165e-6f;
+constexpr int kMaxSplit = 8, kMinSliceSteps = 13;  // every K slice keeps a real K loop
+
+// Returns the tile configuration and sets *S_out (1 = no split-K).  `can_split`: the caller can run a reduce pass.
+int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, int* S_out) {
+    *S_out = 1;
+    const bool forced = g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (geglu ? kCfgs[g_force_cfg].fn_geglu : kCfgs[g_force_cfg].fn);
     auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * batch; };
     if (geglu) {
-        if ((Cout % 256) == 0 && tiles(256, 256) >= 200) return 20;
-    } else {
-        if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
-        // 16x16 level, K too short to split: 128x320 fills every CU (256 tiles, two blocks per CU) where 256x256 leaves
-        // 160 tiles (+20 %)
-        if ((Cout % 320) == 0 && tiles(256, 320) < 200 && tiles(128, 320) >= 200) return 3;
-        if ((Cout % 256) == 0 && tiles(256, 256) >= 150) return Cout == 256 ? 10 : 20;
-        if ((Cout % 128) == 0 && tiles(256, 128) >= 200) return 15;
-        if (M <= 4096 && tiles(128, 128) >= 100) return 19;
+        if (forced) return g_force_cfg;
+        // 256x256 where it fills whole rounds or most of one; between them (257..399 tiles) the second round runs half empty
+        const long long t = (Cout % 256) == 0 ? tiles(256, 256) : 0;
+        if (t >= 400 || (t >= 128 && t <= 256)) return 20;
+        const bool n128 = (Cout % 128) == 0 || Cout >= 512;
+        if (n128 && tiles(128, 128) >= 160) return 0;
+        return tiles(128, 64) >= 384 ? 1 : 2;
     }
-    const bool n128 = (Cout % 128) == 0 || Cout >= 512;
-    if (!geglu && (Cout % 320) == 0 && K >= 1280 && blocks(3) >= 128) return 3;
-    if (n128 && blocks(0) >= 160) return 0;
-    if (blocks(1) >= 384) return 1;
-    return 2;
+    can_split = can_split && batch == 1;
+    int s_lo = 1, s_hi = can_split ? kMaxSplit : 1;
+    if (g_force_splitk > 0 && can_split) {
+        s_lo = g_force_splitk < kMaxSplit ? g_force_splitk : kMaxSplit;
+        while (s_lo > 1 && KT / s_lo < kMinSliceSteps) --s_lo;
+        s_hi = s_lo;
+    }
+    if (!forced && s_lo == 1) {
+        // Layers with whole rounds of the largest tiles (measured in situ: persistent 256x320 / 256x256 tiles, 45-50 % DMA duty,
+        // beat every smaller tile there; the L2 -> LDS path delivers ~64 B/clk/CU, so (BM+BN)*128 B / 64 per K step must stay
+        // well under the MFMA time BM*BN/32 clk)
+        if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
+        if ((Cout % 256) == 0 && (Cout % 320) != 0 && tiles(256, 256) >= 150) return Cout == 256 ? 10 : 20;
+        if ((Cout % 128) == 0 && (Cout % 320) != 0 && tiles(256, 128) >= 200) return 15;
+        if (Cout < 128) return tiles(128, 64) >= 384 ? 1 : 2;  // narrow outputs: not part of the fit
+    }
+    float best = 3.0e38f;
+    int best_cfg = -1;
+    for (const CostRow& r : kCost) {
+        if (forced && r.cfg != g_force_cfg) continue;
+        const TileCfg& c = kCfgs[r.cfg];
+        const long long t = tiles(c.bm, c.bn);
+        for (int S = s_lo; S <= s_hi; ++S) {
+            if (S > 1 && (!c.fn_split || KT / S < kMinSliceSteps)) break;
+            const long long slots = (long long)kNumCUs * r.per_cu;
+            const float rounds = (float)((t * S + slots - 1) / slots);
+            float us = rounds * (r.a_us + r.b_us * (float)KT / (float)S);
+            if (S > 1) us += kReduceUs + kReduceUsPerElem * (float)M * (float)Cout * (float)S;
+            if (us < best) { best = us; best_cfg = r.cfg; *S_out = S; }
+        }
+    }
+    if (best_cfg < 0) { best_cfg = g_force_cfg; *S_out = 1; }  // a forced configuration the model has no row for
+    return best_cfg;
 }
 
 }  // namespace
@@ -699,34 +733,6 @@ extern "C" int ccnet_prof_shapes(double* table, int max_rows) {
     return n;
 }
 
-namespace {
-// split-K plan: deep-K layers whose 256x320 tiling leaves most CUs idle (M <= 8192 at Cout 1280) run S K-slices per
-// tile and a reduce pass.  Returns S (1 = no split) for the tile configuration `cfg`.
-int plan_splitk(const ccnet_conv_params* p, int M, int KT, int batch, int* cfg) {
-    if (p->act == 2 || batch > 1) return 1;
-    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((p->Cout + bn - 1) / bn); };
-    // measured (tools/sweep_splitk.sh, cold weights): 16x16 level (M 8192, 128 tiles of 256x320): S = 2 on the 256x320 tile;
-    // 8x8 level (M 2048): 80 tiles of 256x128 x S = 3 beats 32 tiles of 256x320 x S = 8 by 15-30 % (a third of the fp32
-    // partial-sum traffic, 240 blocks)
-    int S = 1, scfg = 23;
-    const long long t23 = (p->Cout % 320) == 0 ? tiles(256, 320) : 0, t15 = (p->Cout % 128) == 0 ? tiles(256, 128) : 0;
-    if (g_force_splitk > 0) {
-        S = g_force_splitk;
-    } else if (t23 >= 100 && t23 < 200) {
-        S = (int)(256 / t23);
-    } else if (t15 > 0 && t15 < 128) {
-        S = (int)(256 / t15);
-        scfg = 15;
-    } else if (t23 > 0 && t23 < 100) {
-        S = (int)(256 / t23);
-    }
-    if (S > 8) S = 8;
-    while (S > 1 && KT / S < 13) --S;  // every slice keeps a real K loop (K = 1280 at the 8x8 level loses with S = 2)
-    if (S > 1 && (g_force_cfg < 0 || *cfg < 0 || !kCfgs[*cfg].fn_split)) *cfg = scfg;
-    return S;
-}
-}  // namespace
-
 // Output convolution (3x3, stride 1, pad 1, Cin % 64 == 0, Cout <= 8) on the implicit-GEMM kernel: NHWC bf16 in, fp32 NCHW
 // out.  Called by ccnet_conv_out_small (elementwise.hip); w is [Cout][9][Cin] bf16 -- the rows a 32-cout tile reads
 // beyond Cout fall outside the weight descriptor and come back as zeros.
@@ -750,8 +756,8 @@ extern "C" size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p) {
     if (!p || p->C1 <= 0 || p->Cout <= 0 || p->N <= 0) return 0;
     const int KT = p->R * p->R * ((p->C1 + p->C2) / 64);
     const int M = p->N * p->Hout * p->Wout;
-    int cfg = -1;
-    const int S = plan_splitk(p, M, KT, p->batch > 1 ? p->batch : 1, &cfg);
+    int S = 1;
+    (void)plan_conv(M, p->Cout, KT, p->batch > 1 ? p->batch : 1, p->act == 2, true, &S);
     return S > 1 ? (size_t)S * M * p->Cout * sizeof(float) : 0;
 }
 
@@ -818,8 +824,7 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
         (void)hipEventRecord(rec->e0, st);
     }
     const bool geglu = p->act == 2;
-    int cfg_i = pick_cfg(a.M, p->Cout, a.KT * 64, batch, geglu, p->res1 != nullptr);
-    a.splitk = plan_splitk(p, a.M, a.KT, batch, &cfg_i);
+    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, true, &a.splitk);
     if (a.splitk > 1) {
         if (!p->workspace || p->workspace_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return CCNET_EWS;
         a.ws = (float*)p->workspace;

@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--order", type=int, default=-1, help="force tile order: 0 N-fastest, 1 M-fastest")
     ap.add_argument("--persist", type=str, default="1", help="comma list: 1 persistent launches, 0 one block per tile")
     ap.add_argument("--scale", type=float, default=1.0, help="epilogue scale (diagnostic builds key experiments on it)")
+    ap.add_argument("--images", type=int, default=0, help="override the CFG batch of every shape (2 = one image with CFG)")
     ap.add_argument("--cold", action="store_true", help="rotate over 12 weight copies so weights come from HBM")
     args = ap.parse_args()
     from ccnet_amd import lib as _lib
@@ -79,6 +80,8 @@ def main():
     tot_f, tot_t = 0.0, 0.0
     for shape in SHAPES:
         name, N, H, C1, C2, Cout, R, stride, ups = shape[:9]
+        if args.images:
+            N = args.images
         with_res = len(shape) > 9 and shape[9]
         act = shape[10] if len(shape) > 10 else 0
         if args.filter and args.filter not in name:
