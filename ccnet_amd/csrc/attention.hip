@@ -34,6 +34,8 @@ __device__ __forceinline__ s16x4 ds_read_tr16(const char* p) {
 
 // launch bound of 2 waves per SIMD: caps the kernel at 256 registers so hipcc keeps MFMA results in VGPRs (with 512
 // allowed it parks S and O in AGPRs and pays ~160 v_accvgpr moves per tile around the softmax).
+// CAUSAL: key j contributes to query i only for j <= i (the text tower's mask; Sq == Skv there)
+template <bool CAUSAL>
 __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // K0 V0 K1 V1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,13 +125,14 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         }
         // scale into the log2 domain, mask keys beyond Skv (only possible in the last tile)
         const int kbase = t * KV_TILE + 4 * hh;
-        if constexpr (tail) {
+        if constexpr (tail || CAUSAL) {
+            const int klim = CAUSAL ? min(a.Skv, q0 + l31 + 1) : a.Skv;  // this lane's query sees keys < klim
 #pragma unroll
             for (int kbk = 0; kbk < NB; ++kbk)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kbase + kbk * 32 + (e & 3) + 8 * (e >> 2);
-                    if (key >= a.Skv) s[kbk][e] = -INFINITY;
+                    if (key >= klim) s[kbk][e] = -INFINITY;
                 }
         }
         float mx = -INFINITY;  // raw-score maximum of this lane's 32 keys, then of the whole row
@@ -258,8 +261,9 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const __bf16* x, int
 
 }  // namespace
 
-extern "C" int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                                        void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream) {
+namespace {
+int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H,
+                     int Sq, int Skv, float scale, bool causal, void* stream) {
     if (!Q || !K || !V || !O) return CCNET_EINVAL;
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return CCNET_EINVAL;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4)) return CCNET_EINVAL;
@@ -272,9 +276,23 @@ extern "C" int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, i
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv;
     a.scale_log2e = scale * 1.4426950408889634f;
     a.k_bytes = (unsigned)kb; a.v_bytes = (unsigned)vb;
-    hipLaunchKernelGGL(attn_d64_kernel, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
+    if (causal)
+        hipLaunchKernelGGL(attn_d64_kernel<true>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_d64_kernel<false>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
+}
+}  // namespace
+
+extern "C" int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                        void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream) {
+    return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, scale, false, stream);
+}
+
+extern "C" int ccnet_attention_d64_causal_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                               void* O, int ldo, int B, int H, int S, float scale, void* stream) {
+    return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, S, S, scale, true, stream);
 }
 
 extern "C" int ccnet_softmax_rows_bf16(const void* x, int ldx, int rows, int cols, int cols_pad, float scale,

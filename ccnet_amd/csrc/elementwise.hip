@@ -19,6 +19,40 @@ __global__ __launch_bounds__(256) void geglu_kernel(const __bf16* x, int ldx, in
     }
 }
 
+// ------------------------------------------------------------------ text tower pieces (CLIP): activation, embeddings
+// mode 0: x * Phi(x) (erf GELU, hidden_act "gelu"); mode 1: x * sigmoid(1.702 x) ("quick_gelu")
+__global__ __launch_bounds__(256) void gelu_kernel(const __bf16* x, int ldx, int rows, int C, int mode, __bf16* out, int ldo) {
+    const int cols = C / 8;
+    const long long total = (long long)rows * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / cols), c = (int)(idx % cols) * 8;
+        float v[8];
+        unpack8(*(const u32x4*)(x + (long long)r * ldx + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = mode == 0 ? 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f)) : v[e] / (1.0f + __expf(-1.702f * v[e]));
+        *(u32x4*)(out + (long long)r * ldo + c) = pack8(v);
+    }
+}
+
+// out[t][:] = bf16(tok[ids[t]][:] + pos[t % seq][:]); ids outside [0, vocab) give the position row alone (flagged on the host)
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long long* ids, int T, int seq, int vocab, const float* tok,
+                                                           const float* pos, int C, __bf16* out, int ldo) {
+    const int cols = C / 8;
+    const long long total = (long long)T * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int t = (int)(idx / cols), c = (int)(idx % cols) * 8;
+        const long long id = ids[t];
+        const bool ok = id >= 0 && id < vocab;
+        const float* tp = tok + (ok ? id : 0) * C + c;
+        const float* pp = pos + (long long)(t % seq) * C + c;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (ok ? tp[e] : 0.f) + pp[e];
+        *(u32x4*)(out + (long long)t * ldo + c) = pack8(v);
+    }
+}
+
 // ------------------------------------------------------------------ CFG combine + DDIM / DDPM step (fp32)
 __global__ __launch_bounds__(256) void cfg_step_kernel(const float* mo, int cfg_mode, float g, const float* coef,
                                                        const float* noise, float* sample, float* x0_out, int B,
@@ -511,6 +545,25 @@ extern "C" int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* o
     if (!x || !out || rows <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || ldx < 2 * C) return CCNET_EINVAL;
     hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((long long)rows * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)x, ldx, rows, C, (__bf16*)out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_gelu_bf16(const void* x, int ldx, int rows, int C, int mode, void* out, int ldo, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || ldx < C || ldo < C || mode < 0 || mode > 1)
+        return CCNET_EINVAL;
+    hipLaunchKernelGGL(gelu_kernel, dim3(grid_for((long long)rows * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, ldx, rows, C, mode, (__bf16*)out, ldo);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_embed_tokens_bf16(const int64_t* ids, int T, int seq, int vocab, const float* tok, const float* pos,
+                                       int C, void* out, int ldo, void* stream) {
+    if (!ids || !tok || !pos || !out || T <= 0 || seq <= 0 || vocab <= 0 || C <= 0 || (C % 8) || (ldo % 8) || ldo < C)
+        return CCNET_EINVAL;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for((long long)T * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, T, seq, vocab, tok, pos, C, (__bf16*)out, ldo);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

@@ -21,6 +21,7 @@ EXPORTS = [
     "ccnet_linear_f32", "ccnet_cfg_scheduler_step", "ccnet_nchw_f32_to_nhwc_bf16", "ccnet_nhwc_bf16_to_nchw_f32",
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
     "ccnet_set_option", "ccnet_prof_shapes", "ccnet_conv_workspace_bytes", "ccnet_transpose_pad_bf16",
+    "ccnet_attention_d64_causal_bf16", "ccnet_embed_tokens_bf16", "ccnet_gelu_bf16",
 ]
 
 
@@ -72,6 +73,9 @@ def load() -> C.CDLL:
     lib.ccnet_layernorm_bf16.argtypes = [vp, i, i, i, f, vp, vp, vp, i, vp]
     lib.ccnet_geglu_bf16.argtypes = [vp, i, i, i, vp, i, vp]
     lib.ccnet_attention_d64_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, vp]
+    lib.ccnet_attention_d64_causal_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, f, vp]
+    lib.ccnet_embed_tokens_bf16.argtypes = [vp, i, i, i, vp, vp, i, vp, i, vp]
+    lib.ccnet_gelu_bf16.argtypes = [vp, i, i, i, i, vp, i, vp]
     lib.ccnet_softmax_rows_bf16.argtypes = [vp, i, i, i, i, f, vp, i, vp]
     lib.ccnet_transpose_pad_bf16.argtypes = [vp, i, i, i, C.c_int64, vp, i, i, C.c_int64, i, vp]
     lib.ccnet_timestep_embedding.argtypes = [vp, i, i, i, vp, vp, vp]

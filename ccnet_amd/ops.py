@@ -177,6 +177,38 @@ def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: 
     return o
 
 
+def attention_d64_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, S: int, scale: float) -> torch.Tensor:
+    """Causal self-attention (key j <= query i): q/k/v [B*S, >=H*64] (views allowed) -> o [B*S, H*64]."""
+    lib = _l.load()
+    _need_cuda(q, k, v)
+    o = torch.empty((B * S, H * 64), dtype=BF16, device=q.device)
+    _l.check(lib.ccnet_attention_d64_causal_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                                 v.stride(0), o.data_ptr(), o.stride(0), B, H, S, scale, _stream()),
+             "attention_d64_causal")
+    return o
+
+
+def gelu(x2d: torch.Tensor, Cc: int, quick: bool = False) -> torch.Tensor:
+    """erf GELU (or x * sigmoid(1.702 x) with quick=True) over the first Cc columns of bf16 rows."""
+    lib = _l.load()
+    _need_cuda(x2d)
+    out = torch.empty((x2d.shape[0], Cc), dtype=BF16, device=x2d.device)
+    _l.check(lib.ccnet_gelu_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], Cc, int(quick), out.data_ptr(),
+                                 out.stride(0), _stream()), "gelu")
+    return out
+
+
+def embed_tokens(ids: torch.Tensor, seq: int, tok: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """ids int64 [T] (T = B*seq), tok fp32 [vocab, C], pos fp32 [>=seq, C] -> bf16 [T, C] = tok[ids] + pos[t % seq]."""
+    lib = _l.load()
+    _need_cuda(ids, tok, pos)
+    T, Cc = ids.numel(), tok.shape[1]
+    out = torch.empty((T, Cc), dtype=BF16, device=ids.device)
+    _l.check(lib.ccnet_embed_tokens_bf16(ids.data_ptr(), T, seq, tok.shape[0], tok.data_ptr(), pos.data_ptr(), Cc,
+                                         out.data_ptr(), out.stride(0), _stream()), "embed_tokens")
+    return out
+
+
 def softmax_rows(x2d: torch.Tensor, cols: int, scale: float, cols_pad: Optional[int] = None) -> torch.Tensor:
     """Row softmax of scale * x over the first `cols` columns, in place capable; [cols, cols_pad) is zero-filled."""
     lib = _l.load()

@@ -233,3 +233,35 @@ def sample(controlnet, diffusion, scheduler, noise, cond, prompt_embeds, empty_p
     """Functional form of the reference loop for one batch (run_controlnet_inference.py:211-256)."""
     s = Sampler(controlnet, diffusion, scheduler, stage1, guidance_scale, conditioning_scale, scale_factor)
     return s.sample(noise, cond, prompt_embeds, empty_prompt_embeds, acquisition_time, **kw)
+
+
+@torch.no_grad()
+def encode_prompts(text_encoder, input_ids: torch.Tensor) -> torch.Tensor:
+    """`text_encoder(reports.squeeze(1))[0]` (run_controlnet_inference.py:149-150,205): token ids [B,77] or [B,1,77]
+    -> prompt embeddings [B,77,D] on the text tower's device."""
+    ids = input_ids.reshape(-1, input_ids.shape[-1])
+    return text_encoder(ids.to(text_encoder.device))[0]
+
+
+@torch.no_grad()
+def preview_controlnet_sample(cond, controlnet, diffusion, stage1, text_encoder, scheduler, spatial_shape=None,
+                              device=None, scale_factor: float = 1.0, acquisition_time=None, text_condition=None,
+                              controlnet_conditioning_scale: float = 1.0, noise: Optional[torch.Tensor] = None):
+    """The sampling part of `log_controlnet_samples` (util.py:840-931): one image, no CFG, prompt through the text tower
+    (BOS + 76 x EOS ids when `text_condition` is None, :873), every timestep of `scheduler`, AEKL decode of
+    latent / scale_factor (:918).  Returns dict(image, latent, prompt_embeds); the figure / TensorBoard part of the
+    reference function stays with the caller (`ccnet_amd.io.save_controlnet_inference_sample` writes the PNGs)."""
+    device = torch.device(device) if device is not None else cond.device
+    if noise is None:
+        noise = torch.randn((1,) + tuple(spatial_shape))  # :869, CPU generator as upstream
+    if text_condition is None:
+        ids = torch.cat((49406 * torch.ones(1, 1), 49407 * torch.ones(1, 76)), 1).long()
+    else:
+        ids = text_condition
+    prompt_embeds = encode_prompts(text_encoder, ids.to(device))
+    s = Sampler(controlnet, diffusion, scheduler, getattr(stage1, "model", stage1), guidance_scale=None,
+                conditioning_scale=controlnet_conditioning_scale, scale_factor=scale_factor, cfg=False)
+    acq = None if acquisition_time is None else acquisition_time.reshape(-1).to(device)
+    res = s.sample(noise.to(device), cond.to(device), prompt_embeds, prompt_embeds[:1], acq)
+    res["prompt_embeds"] = prompt_embeds
+    return res

@@ -121,6 +121,17 @@ int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo
 int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                              void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream);
 
+/* Causal self-attention (key j <= query i), same layout and kernel: the CLIP text tower's masked attention
+ * (transformers CLIPTextModel, called at run_controlnet_inference.py:149,205 as text_encoder(input_ids)). */
+int ccnet_attention_d64_causal_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                    void* O, int ldo, int B, int H, int S, float scale, void* stream);
+
+/* Text tower pieces (run_controlnet_inference.py:126,149): token + position embedding lookup (fp32 tables, bf16 rows out;
+ * row t uses position t % seq) and the MLP activation (mode 0 = erf GELU, 1 = quick_gelu). */
+int ccnet_embed_tokens_bf16(const int64_t* ids, int T, int seq, int vocab, const float* tok, const float* pos, int C,
+                            void* out, int ldo, void* stream);
+int ccnet_gelu_bf16(const void* x, int ldx, int rows, int C, int mode, void* out, int ldo, void* stream);
+
 /* Generic-head-dim attention fallback (single head of 512 / 768 channels in the repo's YAML geometry,
  * configs/controlnet/controlnet_v1.yaml:11): scores by ccnet_conv_gemm_bf16 (batched, scale in the epilogue), this row
  * softmax (in place capable; columns [cols, cols_pad) are written as zeros), V^T by ccnet_transpose_pad_bf16

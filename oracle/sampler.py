@@ -88,6 +88,27 @@ def sample(controlnet, diffusion, scheduler, noise, cond, prompt_embeds, empty_p
     return res
 
 
+@torch.no_grad()
+def preview_sample(cond, controlnet, diffusion, stage1, text_forward, scheduler, noise, scale_factor: float = 1.0,
+                   acquisition_time=None, text_condition=None, conditioning_scale: float = 1.0):
+    """util.py:840-931 (log_controlnet_samples) without the figure: one image, no CFG, the prompt run through the text
+    tower (`text_forward(ids) -> hidden states`); with no prompt the ids are BOS followed by 76 EOS (:873).  The initial
+    latent is passed in instead of drawn at :869.  Returns dict(latent, image, prompt_embeds)."""
+    if text_condition is None:
+        ids = torch.cat((49406 * torch.ones(1, 1), 49407 * torch.ones(1, 76)), 1).long()
+    else:
+        ids = text_condition
+    prompt_embeds = text_forward(ids.squeeze(1))
+    latent = noise.clone()
+    for t in scheduler.timesteps:
+        timestep = torch.asarray((t,))
+        down, mid = sample_from_controlnet(controlnet, latent, cond, timestep, prompt_embeds, acquisition_time,
+                                           conditioning_scale)
+        noise_pred = sample_from_ldm(diffusion, latent, timestep, prompt_embeds, down, mid, acquisition_time)
+        latent, _ = scheduler.step(noise_pred, t, latent)
+    return {"latent": latent, "image": stage1.decode(latent / scale_factor), "prompt_embeds": prompt_embeds}
+
+
 def interval_mapping(image, from_min, from_max, to_min, to_max, is_clipped=True):
     """util.py:1162-1173."""
     scaled = np.array((image - from_min) / float(from_max - from_min), dtype=float)

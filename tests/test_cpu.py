@@ -1,5 +1,6 @@
 """CPU-side suite (no GPU): the oracle against known-answer constants and the committed golden vectors, the host
 logic of the product (schedulers, state-dict surface, sharding), and the C-ABI library's exported symbols."""
+import json
 import math
 import os
 import re
@@ -454,3 +455,61 @@ def test_autoencoder_attention_state_dict_matches_oracle():
         a, b = p.state_dict(), o.state_dict()
         assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
         assert any(".to_q." in k for k in a)
+
+
+# ------------------------------------------------------------------ §8(f)4: text tower (oracle pin + host surface)
+def test_text_oracle_is_pinned_to_transformers():
+    """The oracle's CLIP text tower against transformers' own CLIPTextModel (the module the reference imports,
+    run_controlnet_inference.py:22,126) on seeded random weights: both activations, both EOS pooling rules."""
+    tr = pytest.importorskip("transformers")
+    from oracle.text_encoder import clip_text_forward
+    for act, eos in (("gelu", 999), ("quick_gelu", 2)):
+        torch.manual_seed(5)
+        cfg = tr.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                                num_attention_heads=2, hidden_act=act, eos_token_id=eos, bos_token_id=998, pad_token_id=1)
+        hf = tr.CLIPTextModel(cfg).eval()
+        ids = torch.randint(3, 990, (2, 77))
+        ids[:, 30] = 999
+        with torch.no_grad():
+            o = hf(ids)
+        hid, pool = clip_text_forward(hf.state_dict(), ids, 2, act, cfg.layer_norm_eps, eos)
+        assert (hid - o.last_hidden_state).abs().max().item() < 1e-4
+        assert (pool - o.pooler_output).abs().max().item() < 1e-4
+
+
+def test_text_tower_surface_and_known_parameter_count(tmp_path):
+    from safetensors.torch import save_file
+    from ccnet_amd.text_encoder import CLIPTextModel
+    from ccnet_amd.lib import CcnetError
+    # SD-2.1-base text_encoder/config.json geometry: 340,387,840 parameters (the published size of that tower)
+    with torch.device("meta"):
+        big = CLIPTextModel(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
+                            hidden_act="gelu", projection_dim=512)
+    assert sum(p.numel() for p in big.parameters()) == 340_387_840
+    assert len(big.state_dict()) == 2 + 23 * 16 + 2
+    small = dict(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                 hidden_act="gelu")
+    m = CLIPTextModel(**small)
+    sd = m.state_dict()
+    # both key generations load: transformers 4.x prefixes `text_model.` and carries a position_ids buffer
+    bare = {k[len("text_model."):]: v for k, v in sd.items()}
+    m2 = CLIPTextModel(**small)
+    m2.load_state_dict(bare)
+    old = dict(sd)
+    old["text_model.embeddings.position_ids"] = torch.arange(77).unsqueeze(0)
+    m2.load_state_dict(old)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # local folder round trip; hub ids raise
+    d = tmp_path / "sd21" / "text_encoder"
+    d.mkdir(parents=True)
+    (d / "config.json").write_text(json.dumps(dict(small, architectures=["CLIPTextModel"], model_type="clip_text_model")))
+    save_file({k: v.contiguous() for k, v in bare.items()}, str(d / "model.safetensors"))
+    m3 = CLIPTextModel.from_pretrained(str(tmp_path / "sd21"), subfolder="text_encoder")
+    assert m3.config.hidden_size == 128 and not m3.training
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+    with pytest.raises(OSError):
+        CLIPTextModel.from_pretrained("stabilityai/stable-diffusion-2-1-base", subfolder="text_encoder")
+    with pytest.raises(CcnetError):  # no CPU path
+        m3(torch.zeros(1, 77, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        CLIPTextModel(hidden_size=128, num_attention_heads=4)

@@ -516,3 +516,44 @@ def test_conv_dispatch_sweep(cuda):
             ref = a * F.gelu(gate)
             assert out.C == Cout // 2
         _close(_nchw(out, ref.shape[1]), ref, atol=3e-2, what=what)
+
+
+# ------------------------------------------------------------------ text tower kernels
+@pytest.mark.parametrize("case", [(2, 2, 77), (1, 3, 200), (3, 1, 128), (2, 2, 5)])
+def test_causal_attention_matches_masked_softmax(case):
+    B, H, S = case
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(700 + S)
+    qkv = torch.randn(B * S, 3 * H * 64, generator=g).to(torch.bfloat16).to(dev)
+    q, k, v = qkv[:, :H * 64], qkv[:, H * 64:2 * H * 64], qkv[:, 2 * H * 64:]
+    out = ops.attention_d64_causal(q, k, v, B, H, S, 0.125).float()
+    qf, kf, vf = (t.float().view(B, S, H, 64).transpose(1, 2) for t in (q, k, v))
+    mask = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 0.125 + mask, -1) @ vf).transpose(1, 2).reshape(B * S, H * 64)
+    _close(out, ref, atol=2e-2, what=f"causal attention {case}")
+    # the first query sees only the first key: its output is V[0] exactly (bf16 round trip aside)
+    first = out.view(B, S, H * 64)[:, 0]
+    _close(first, v.float().view(B, S, H * 64)[:, 0], atol=1e-6, rtol=2.0 ** -8, what="first row")
+
+
+@pytest.mark.parametrize("quick", [False, True])
+def test_gelu_modes(quick):
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    x = (torch.randn(77 * 3, 512 + 64, generator=torch.Generator().manual_seed(71)) * 3).to(torch.bfloat16).to(dev)
+    out = ops.gelu(x, 512, quick).float()
+    xf = x[:, :512].float()
+    ref = xf * torch.sigmoid(1.702 * xf) if quick else F.gelu(xf)
+    _close(out, ref, atol=1e-3, what="gelu")
+
+
+def test_embed_tokens():
+    ops = _ops()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(72)
+    tok, pos = torch.randn(500, 128, generator=g).to(dev), torch.randn(77, 128, generator=g).to(dev)
+    ids = torch.randint(0, 500, (4 * 77,), generator=g).to(dev)
+    out = ops.embed_tokens(ids, 77, tok, pos).float()
+    ref = (tok[ids] + pos.repeat(4, 1)).to(torch.bfloat16).float()
+    assert torch.equal(out, ref)

@@ -381,3 +381,87 @@ def test_sampler_on_the_diffusers_surface(cuda):
     ps_db = psnr(res["image"], ref["image"])
     print(f"diffusers-surface final image PSNR {ps_db:.1f} dB")
     assert ps_db >= 40.0
+
+
+# ------------------------------------------------------------------ §8(f)4: the CLIP text tower
+@pytest.mark.parametrize("geom", [
+    dict(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+         hidden_act="quick_gelu", eos_token_id=2),
+    # SD-2.1 text_encoder geometry (ViT-H text tower: 1024 wide, 16 heads, erf GELU) at 4 of its 23 layers
+    dict(vocab_size=2000, hidden_size=1024, intermediate_size=4096, num_hidden_layers=4, num_attention_heads=16,
+         hidden_act="gelu", eos_token_id=1999),
+])
+def test_text_tower_matches_oracle(geom):
+    from ccnet_amd.text_encoder import CLIPTextModel
+    from oracle.text_encoder import clip_text_forward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(123)
+    m = CLIPTextModel(**geom).eval()
+    with torch.no_grad():  # trained-like statistics: non-trivial norms and biases
+        for n, p in m.named_parameters():
+            if "layer_norm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+            elif "embedding" in n:
+                p.copy_(0.5 * torch.randn_like(p))
+    V = geom["vocab_size"]
+    ids = torch.randint(3, V - 2, (3, 77))
+    ids[:, 0] = V - 2
+    for b, n in enumerate((5, 40, 76)):  # EOS then padding, as the tokenizer pads prompts to 77
+        ids[b, n] = V - 1
+        ids[b, n + 1:] = V - 1 if geom["eos_token_id"] != 2 else 0
+    ref, ref_pool = clip_text_forward(m.state_dict(), ids, geom["num_attention_heads"], geom["hidden_act"], 1e-5,
+                                      geom["eos_token_id"])
+    m = m.to(dev)
+    out = m(ids.to(dev))
+    hid, pool = out[0].cpu(), out.pooler_output.cpu()
+    assert hid.shape == ref.shape and hid.dtype == torch.float32
+    # bf16 residual stream over the layers: tolerance relative to the O(1) post-LayerNorm output
+    err = (hid - ref).abs()
+    assert err.max().item() < 0.08 and err.mean().item() < 0.01, (err.max().item(), err.mean().item())
+    assert (pool - ref_pool).abs().max().item() < 0.08
+    # second call (packed weights cached) is bit-identical; an in-place weight update invalidates the cache
+    assert torch.equal(m(ids.to(dev))[0].cpu(), hid)
+    with torch.no_grad():
+        m.text_model.final_layer_norm.bias.add_(1.0)
+    assert (m(ids.to(dev))[0].cpu() - hid - 1.0).abs().max().item() < 0.05
+    # tuple form and the reference's reshape of [B,1,77] ids
+    assert torch.equal(m(ids.unsqueeze(1).squeeze(1).to(dev), return_dict=False)[0].cpu(), m(ids.to(dev))[0].cpu())
+
+
+def test_preview_sample_with_text_tower(cuda):
+    """log_controlnet_samples' sampling part (util.py:840-931): default BOS + 76 x EOS prompt through the text tower, one
+    image, no CFG, DDIM, AEKL decode -- against the oracle's restatement with the oracle text tower."""
+    import ccnet_amd.schedulers as ps
+    import oracle.schedulers as osch
+    from ccnet_amd.sampling import preview_controlnet_sample
+    from ccnet_amd.text_encoder import CLIPTextModel
+    from oracle.sampler import preview_sample
+    from oracle.text_encoder import clip_text_forward
+    pc, oc = build_pair("controlnet", {**TINY, **TINY_CE}, 31, cuda, acq=True)
+    pu, ou = build_pair("unet", TINY, 32, cuda, acq=True)
+    pv, ov = build_pair("vae", TINY_VAE, 33, cuda)
+    torch.manual_seed(34)
+    geom = dict(hidden_size=64, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1, hidden_act="gelu")
+    te = CLIPTextModel(**geom).eval()  # full 49408-token vocabulary: the default prompt uses ids 49406 / 49407
+    with torch.no_grad():
+        for n, p in te.named_parameters():
+            if "embedding" in n:
+                p.copy_(0.5 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in te.state_dict().items()}
+    _, _, cond = _inputs(1, cuda, seed=35)
+    noise = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(36))
+    acq = torch.tensor([400.0])
+    psch, osc = ps.DDIMScheduler(clip_sample=False, **SCHED), osch.DDIMScheduler(clip_sample=False, **SCHED)
+    psch.set_timesteps(8)
+    osc.set_timesteps(8)
+    res = preview_controlnet_sample(cond, pc, pu, pv, te.to(cuda), psch, device=cuda, scale_factor=0.5,
+                                    acquisition_time=acq, controlnet_conditioning_scale=0.8, noise=noise)
+    ref = preview_sample(cond, oc, ou, ov, lambda ids: clip_text_forward(sd, ids, 1, "gelu", 1e-5, 49407)[0], osc, noise,
+                         scale_factor=0.5, acquisition_time=acq, conditioning_scale=0.8)
+    assert (res["prompt_embeds"].cpu() - ref["prompt_embeds"]).abs().max().item() < 0.08
+    assert (res["latent"].cpu() - ref["latent"]).abs().max().item() <= 0.1
+    db = psnr(res["image"], ref["image"])
+    print(f"preview PSNR {db:.1f} dB")
+    assert db >= 40.0
