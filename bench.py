@@ -120,8 +120,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every launch from the host (rocprofv3 --pmc passes: counter collection crashes on graph replay)")
     ap.add_argument("--shapes", type=str, default="", help="write the per-shape conv timing table to this file")
+    ap.add_argument("--backend", type=str, default="nccl",
+                    help="process-group backend; 'gloo' + fewer GPUs than ranks = a rehearsal of the N > 1 code path with "
+                         "several ranks sharing a GPU (RCCL refuses that); its numbers mean nothing")
     args = ap.parse_args()
 
+    if os.environ.get("CCNET_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack if the run takes this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CCNET_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,12 +136,19 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
             sys.exit(2)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        print(f"bench.py: local rank {local_rank} has no GPU ({ndev} visible)", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from ccnet_amd import ops
     from ccnet_amd.sampling import Sampler, to_uint8
@@ -168,10 +181,12 @@ def main():
                            b.get("acquisition_time"))
         u8 = to_uint8(r["image"])
         if dist is not None:  # gather generated latents + slices for downstream FRD/FID (one exchange per batch)
-            lat = torch.empty((world,) + tuple(r["latent"].shape), dtype=r["latent"].dtype, device=dev)
-            img = torch.empty((world,) + tuple(u8.shape), dtype=u8.dtype, device=dev)
-            dist.all_gather_into_tensor(lat, r["latent"].contiguous())
-            dist.all_gather_into_tensor(img, u8.contiguous())
+            # concatenated along the batch axis ([world * B, ...]): the form every backend accepts
+            gdev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo rehearsal: its GPU all-gather hangs on ROCm
+            lat = torch.empty((world * B,) + tuple(r["latent"].shape[1:]), dtype=r["latent"].dtype, device=gdev)
+            img = torch.empty((world * B,) + tuple(u8.shape[1:]), dtype=u8.dtype, device=gdev)
+            dist.all_gather_into_tensor(lat, r["latent"].contiguous().to(gdev))
+            dist.all_gather_into_tensor(img, u8.contiguous().to(gdev))
             return lat, img
         return r["latent"], u8
 
@@ -218,7 +233,7 @@ def main():
                 "measured": "eager pass over one batch after the timed region, HIP events around every launch "
                             f"({tp:.2f} s wall for that pass)"}
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
