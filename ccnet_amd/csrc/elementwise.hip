@@ -151,13 +151,18 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int ldx
 // loads in flight.  A operand = w (lane: feature n0 + (l & 31), k-slot l >> 5), B operand = x (lane: batch row
 // l & 31, same k-slot); element e of a lane's float4 feeds MFMA e of the step, so the k order inside an 8-wide
 // step is permuted identically for both operands.
-__global__ __launch_bounds__(64) void linear_f32_mfma_kernel(const float* x, int ldx, int B, int b0, int K,
-                                                              const float* w, const float* bias, int Nout,
-                                                              int silu_in, int silu_out, const float* add,
-                                                              int ldadd, float* out, int ldo) {
-    const int lane = threadIdx.x & 63;
-    const int n0 = blockIdx.x * 32;  // one wave per workgroup: the tile count is what fills the chip
+// The four waves of a workgroup split K (a 1280-feature layer is only 40 tiles: without the split 40 waves stream
+// 160 KB each, 40 us); their partial tiles are summed through LDS in wave order.
+__global__ __launch_bounds__(256) void linear_f32_mfma_kernel(const float* x, int ldx, int B, int b0, int K,
+                                                               const float* w, const float* bias, int Nout,
+                                                               int silu_in, int silu_out, const float* add,
+                                                               int ldadd, float* out, int ldo) {
+    __shared__ float part[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 32;
     if (n0 >= Nout) return;
+    const int Kw = ((K + 3) / 4 + 7) / 8 * 8;  // K slice of a wave, a multiple of the 8-wide step
+    const int kbeg = min(K, wave * Kw), kend = min(K, kbeg + Kw);
     const int l31 = lane & 31, hh = lane >> 5;
     const int n = min(n0 + l31, Nout - 1);        // clamped rows are computed and discarded
     const int b = min(b0 + l31, B - 1);
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(64) void linear_f32_mfma_kernel(const float* x, int
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    int k = 0;
-    for (; k + 32 <= K; k += 32) {
+    int k = kbeg;
+    for (; k + 32 <= kend; k += 32) {
         f32x4 wv[4], xv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { wv[u] = *(const f32x4*)(wr + k + 8 * u); xv[u] = *(const f32x4*)(xr + k + 8 * u); }
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64) void linear_f32_mfma_kernel(const float* x, int
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][e], xe, acc, 0, 0, 0);
             }
     }
-    for (; k < K; k += 8) {
+    for (; k < kend; k += 8) {
         const f32x4 wv = *(const f32x4*)(wr + k), xv = *(const f32x4*)(xr + k);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -187,6 +192,16 @@ __global__ __launch_bounds__(64) void linear_f32_mfma_kernel(const float* x, int
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e], xe, acc, 0, 0, 0);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += part[v][e][lane];
     // D[i = feature][j = batch row]: lane holds column j = l31, rows i = (reg & 3) + 8 * (reg >> 2) + 4 * hh
     const int bo = b0 + l31;
     if (bo >= B) return;
@@ -591,10 +606,12 @@ extern "C" int ccnet_linear_f32(const float* x, int ldx, int B, int K, const flo
                                 int silu_in, int silu_out, const float* add, int ldadd, float* out, int ldo,
                                 void* stream) {
     if (!x || !w || !out || B <= 0 || K <= 0 || Nout <= 0) return CCNET_EINVAL;
-    if (K >= 64 && (K % 8) == 0 && (ldx % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
+    // up to 8 rows (one image with CFG ... 4 images): a wave per output feature streams each weight row once and fills the
+    // chip (1280 waves for a 1280-feature layer); beyond that the matrix-core tiles reuse the weights over 32 rows
+    if (B > 8 && K >= 64 && (K % 8) == 0 && (ldx % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
         const int tasks = (Nout + 31) / 32;
         for (int b0 = 0; b0 < B; b0 += 32) {
-            hipLaunchKernelGGL(linear_f32_mfma_kernel, dim3(tasks), dim3(64), 0, (hipStream_t)stream, x, ldx,
+            hipLaunchKernelGGL(linear_f32_mfma_kernel, dim3(tasks), dim3(256), 0, (hipStream_t)stream, x, ldx,
                                B, b0, K, w, bias, Nout, silu_in, silu_out, add, ldadd, out, ldo);
             CCNET_LAUNCH_CHECK();
         }

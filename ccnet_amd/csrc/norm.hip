@@ -87,19 +87,39 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
     __shared__ float s_mean[64], s_rstd[64];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    if (tid < a.groups) {
-        float mean = 0.f, m2 = 0.f, cnt = 0.f;
-        for (int k = 0; k < a.chunks; ++k) {
-            const float* w = a.ws + (((long long)n * a.chunks + k) * a.groups + tid) * 2;
-            const int q0 = k * a.ppc, q1 = min(a.HW, q0 + a.ppc);
-            const float cb = (float)((q1 - q0) * a.cpg);
-            const float delta = w[0] - mean, tot = cnt + cb;
-            mean += delta * (cb / tot);
-            m2 += w[1] + delta * delta * (cnt * cb / tot);
-            cnt = tot;
+    {
+        // Chan merge of the per-chunk (mean, M2) partials: `per` lanes per group take every per-th chunk, then combine
+        // pairwise (a serial walk over 64 chunks was 64 dependent L2 round trips, ~20 us with one image in flight)
+        int per = 1;
+        while (per * 2 * a.groups <= GN_THREADS && per < 64) per *= 2;
+        const int g = tid / per, j = tid % per;
+        if (g < a.groups) {
+            float mean = 0.f, m2 = 0.f, cnt = 0.f;
+            for (int k = j; k < a.chunks; k += per) {
+                const float* w = a.ws + (((long long)n * a.chunks + k) * a.groups + g) * 2;
+                const int q0 = k * a.ppc, q1 = min(a.HW, q0 + a.ppc);
+                const float cb = (float)((q1 - q0) * a.cpg);
+                const float delta = w[0] - mean, tot = cnt + cb;
+                mean += delta * (cb / tot);
+                m2 += w[1] + delta * delta * (cnt * cb / tot);
+                cnt = tot;
+            }
+            for (int o = 1; o < per; o *= 2) {
+                const float mean_b = __shfl_xor(mean, o), m2_b = __shfl_xor(m2, o), cnt_b = __shfl_xor(cnt, o);
+                const float tot = cnt + cnt_b;
+                if (tot > 0.f) {
+                    // symmetric form: both lanes of a pair compute the same value
+                    const float delta = mean_b - mean;
+                    mean = (mean * cnt + mean_b * cnt_b) / tot;
+                    m2 = m2 + m2_b + delta * delta * (cnt * cnt_b / tot);
+                }
+                cnt = tot;
+            }
+            if (j == 0) {
+                s_mean[g] = mean;
+                s_rstd[g] = rsqrtf(m2 / cnt + a.eps);
+            }
         }
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(m2 / cnt + a.eps);
     }
     __syncthreads();
     // a thread owns a fixed 8-channel column: its scale / shift live in registers, rows are streamed four at a time
