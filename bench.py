@@ -230,7 +230,8 @@ def main():
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                 "launches": int(launches), "kernel_ms_total": round(ms, 3),
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
-                "measured": "eager pass over one batch after the timed region, HIP events around every launch "
+                "measured": "eager pass over one batch after the timed region, HIP events around every launch, the "
+                            "ControlNet / UNet-encoder stream overlap off so that launches do not share CUs "
                             f"({tp:.2f} s wall for that pass)"}
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -248,6 +249,7 @@ def main():
                                    f"batch {B} per GPU (CFG batch {2 * B}), 512^2 slices (64x64x4 latent), SD-2.1-base "
                                    "geometry + acq-time MLP + stage1 AEKL decode; seeded random weights",
                        "batch_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": 7.0,
+                       "controlnet_unet_encoder_overlap": bool(sampler.overlap),
                        "sharding": f"seed-indexed contiguous blocks over {world} rank(s), all_gather of latents+uint8"},
         }
         if roof is not None:

@@ -539,6 +539,11 @@ class DiffusionModelUNet(_Trunk):
         if mid_add is not None:
             h = h[1]
         ai += 1
+        return self._decode(pk, h, skips, tall, kvs, S, ai)
+
+    def _decode(self, pk, h, skips, tall, kvs, S, ai):
+        """Up blocks (each resnet reads its skip as the second source of a channel concat) and the output head."""
+        skips = list(skips)
         for blk in self.up_blocks:
             has_att = hasattr(blk, "attentions")
             for j, r in enumerate(blk.resnets):
@@ -552,6 +557,35 @@ class DiffusionModelUNet(_Trunk):
                 h = ops.conv(h, uw, ub, h.C, R=3, ups=2)
         h = ops.groupnorm(h, pk["out_norm"][0], pk["out_norm"][1], self.norm_num_groups, self.norm_eps, True)
         return ops.conv_out_small(h, pk["out_conv"][0], pk["out_conv"][1], self.out_channels)
+
+    # ---- two-phase form for a sampler that overlaps this network's encoder with the ControlNet (sampling.Sampler):
+    # upstream's trunk never sees the ControlNet residuals (they are added to the skip copies and to the middle block's
+    # output only), so encoder + middle block depend on (x, t) alone and can run beside the ControlNet; the ControlNet's
+    # zero-convolutions then write skip + residual directly (their res1 operand), and decode_phase() continues from there.
+    @torch.no_grad()
+    def encode_phase(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
+                     class_labels: Optional[torch.Tensor] = None, _ctx_kv=None, _x_batch: Optional[int] = None):
+        pk = self._pk or self._pack()
+        if not x.is_cuda:
+            raise CcnetError("ccnet_amd.DiffusionModelUNet runs on the GPU only (no CPU fallback)")
+        x = x.contiguous().float()
+        B = _x_batch or x.shape[0]
+        tall = self._embedding(pk, timesteps, class_labels, B)
+        kvs, S = self.context_kv(context) if _ctx_kv is None else _ctx_kv
+        c0 = self.block_out_channels[0]
+        w, b = pk["conv_in"]
+        s0 = ops.conv_in_small(x, B, w, b, c0, c0)
+        h, skips, ai = self._encode(pk, s0, tall, kvs, S, None)
+        h = self._mid(pk, h, tall, kvs[ai], S)
+        return {"pk": pk, "tall": tall, "kvs": kvs, "S": S, "ai": ai + 1, "skips": [s0] + skips, "h": h}
+
+    @torch.no_grad()
+    def decode_phase(self, st, skips: Optional[Sequence[Act]] = None, h: Optional[Act] = None) -> torch.Tensor:
+        """Decoder over `skips` / `h` (default: the encoder's own, i.e. no ControlNet).  Returns fp32 NCHW."""
+        skips = st["skips"] if skips is None else skips
+        if len(skips) != len(st["skips"]):
+            raise ValueError(f"expected {len(st['skips'])} skips, got {len(skips)}")
+        return self._decode(st["pk"], st["h"] if h is None else h, skips, st["tall"], st["kvs"], st["S"], st["ai"])
 
 
 class ControlNet(_Trunk):
@@ -624,8 +658,11 @@ class ControlNet(_Trunk):
     @torch.no_grad()
     def forward_native(self, x, timesteps, controlnet_cond, conditioning_scale: float = 1.0, context=None,
                        class_labels=None, _ctx_kv=None, _cond_emb: Optional[Act] = None,
-                       _x_batch: Optional[int] = None):
-        """Same computation as forward(); returns the residuals as NHWC bf16 `Act`s."""
+                       _x_batch: Optional[int] = None, _unet_state=None, _before_zero=None):
+        """Same computation as forward(); returns the residuals as NHWC bf16 `Act`s.  With `_unet_state` (the result of
+        DiffusionModelUNet.encode_phase on the same inputs) the zero-convolutions add the UNet's skips / middle output
+        in their epilogue and the returned tensors are skip + residual, ready for decode_phase(); `_before_zero()` is
+        called after the trunk and before those launches (the sampler's stream join)."""
         pk = self._pk or self._pack()
         if not x.is_cuda:
             raise CcnetError("ccnet_amd.ControlNet runs on the GPU only (no CPU fallback)")
@@ -645,9 +682,14 @@ class ControlNet(_Trunk):
         skips = [s0] + skips
         h = self._mid(pk, h, tall, kvs[ai], S)
         sc = float(conditioning_scale)
-        down = [ops.conv(s, zw, zb, s.C, R=1, pad=0, scale=sc) for s, (zw, zb) in zip(skips, pk["zero"])]
+        if _before_zero is not None:
+            _before_zero()
+        us = _unet_state["skips"] if _unet_state is not None else [None] * len(skips)
+        if len(us) != len(skips):
+            raise ValueError(f"UNet state holds {len(us)} skips, the ControlNet produces {len(skips)}")
+        down = [ops.conv(s, zw, zb, s.C, R=1, pad=0, scale=sc, res1=u) for s, (zw, zb), u in zip(skips, pk["zero"], us)]
         zw, zb = pk["zero_mid"]
-        mid = ops.conv(h, zw, zb, h.C, R=1, pad=0, scale=sc)
+        mid = ops.conv(h, zw, zb, h.C, R=1, pad=0, scale=sc, res1=_unet_state["h"] if _unet_state is not None else None)
         return down, mid
 
     def forward(self, x, timesteps, controlnet_cond, conditioning_scale: float = 1.0, context=None,

@@ -3,6 +3,8 @@
 # usage: tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/{stats,fetch,write}, summaries under gpurun_out/
 tag=$1; root=$PWD; out=$root/gpurun_out/prof_$tag
 CMD="python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-prof"
+# per-kernel durations and counters are taken with the ControlNet / UNet-encoder overlap off (isolated kernels)
+export CCNET_OVERLAP=0
 mkdir -p $out && cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/stats.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $CMD --no-graph > $out/fetch.log 2>&1 || exit 1
