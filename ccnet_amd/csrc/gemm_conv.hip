@@ -617,7 +617,7 @@ struct CostRow { int cfg; float a_us, b_us; int per_cu; };
 const CostRow kCost[] = {{19, 4.94f, 0.5370f, 1}, {15, 7.85f, 0.7451f, 1}, {0, 6.48f, 0.9108f, 2},
                          {3, 8.93f, 1.3780f, 1},  {20, 11.80f, 1.4901f, 1}, {23, 13.00f, 1.7703f, 1}};
 constexpr float kReduceUs = 3.14f, kReduceUsPerElem = 1.165e-6f;
-constexpr int kMaxSplit = 8, kMinSliceSteps = 13;  // every K slice keeps a real K loop
+constexpr int kMaxSplit = 32, kMinSliceSteps = 13;  // every K slice keeps a real K loop
 
 // Returns the tile configuration and sets *S_out (1 = no split-K).  `can_split`: the caller can run a reduce pass.
 int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, int* S_out) {

@@ -4,6 +4,7 @@ Random data (never zeros: MI355X clocks higher on zero operands), timed with eve
 import argparse
 import math
 import os
+import re
 import sys
 
 import torch
@@ -84,7 +85,7 @@ def main():
             N = args.images
         with_res = len(shape) > 9 and shape[9]
         act = shape[10] if len(shape) > 10 else 0
-        if args.filter and args.filter not in name:
+        if args.filter and not re.search(args.filter, name):
             continue
         g = torch.Generator(device=dev).manual_seed(1)
         x1 = Act(torch.randn(N * H * H, C1, device=dev, generator=g).to(torch.bfloat16), N, H, H, C1)
