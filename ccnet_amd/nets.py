@@ -317,6 +317,35 @@ class _Trunk(nn.Module):
         # every resnet's time_emb_proj(silu(emb)) in one launch; resnets take column slices
         return ops.linear_f32(semb, pk["tproj_w"], pk["tproj_b"])
 
+    @torch.no_grad()
+    def embedding_table(self, timesteps, class_labels, B, max_bytes: int = 1 << 30):
+        """Every step's time-embedding projections at once: [T, B, sum of resnet couts] fp32 (row t = what _embedding
+        returns for timesteps[t]), or None when the table would exceed `max_bytes`.  The class-embedding MLP and the
+        three time-embedding linears depend on (t, image) only, so a sampler evaluates them once per batch (weights read
+        once instead of once per step: at one image that is 12 of a step's launches and ~100 MB of fp32 weights per network)."""
+        pk = self._pk or self._pack()
+        dev = pk["freqs"].device
+        t = torch.as_tensor([float(v) for v in timesteps], dtype=torch.float32, device=dev)
+        T = t.numel()
+        if T * B * pk["tproj_w"].shape[0] * 4 > max_bytes:
+            return None
+        c0 = self.block_out_channels[0]
+        t_emb = ops.timestep_embedding(t, T, c0, pk["freqs"])
+        h = ops.linear_f32(t_emb, pk["te0"][0], pk["te0"][1], silu_out=True)
+        add = None
+        if self.num_class_embeds is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            if "class_table" in pk:
+                add = pk["class_table"][class_labels.to(dev).long().reshape(-1)]
+            else:
+                cl = class_labels.to(device=dev, dtype=torch.float32).reshape(B, 1).contiguous()
+                c1 = ops.linear_f32(cl, pk["ce0"][0], pk["ce0"][1], silu_out=True)
+                add = ops.linear_f32(c1, pk["ce2"][0], pk["ce2"][1])
+            add = add.repeat(T, 1)  # row t*B + b
+        semb = ops.linear_f32(h.repeat_interleave(B, 0), pk["te2"][0], pk["te2"][1], add=add, silu_out=2)
+        return ops.linear_f32(semb, pk["tproj_w"], pk["tproj_b"]).view(T, B, -1)
+
     def _context(self, context, B):
         if context is None:
             raise ValueError("context is required (with_conditioning=True)")
@@ -506,7 +535,7 @@ class DiffusionModelUNet(_Trunk):
     @torch.no_grad()
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
                 class_labels: Optional[torch.Tensor] = None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, _ctx_kv=None, _x_batch: Optional[int] = None):
+                mid_block_additional_residual=None, _ctx_kv=None, _x_batch: Optional[int] = None, _tall=None):
         """x fp32 NCHW [Bx, Cin, h, w]; the network batch is `_x_batch or Bx` (image n reads x[n % Bx], which lets a
         CFG sampler pass the un-duplicated latent).  Returns fp32 NCHW [B, Cout, h, w]."""
         pk = self._pk or self._pack()
@@ -515,7 +544,7 @@ class DiffusionModelUNet(_Trunk):
             raise CcnetError("ccnet_amd.DiffusionModelUNet runs on the GPU only (no CPU fallback)")
         x = x.contiguous().float()
         B = _x_batch or x.shape[0]
-        tall = self._embedding(pk, timesteps, class_labels, B)
+        tall = _tall if _tall is not None else self._embedding(pk, timesteps, class_labels, B)
         if _ctx_kv is None:
             kvs, S = self.context_kv(context)
         else:
@@ -564,13 +593,14 @@ class DiffusionModelUNet(_Trunk):
     # zero-convolutions then write skip + residual directly (their res1 operand), and decode_phase() continues from there.
     @torch.no_grad()
     def encode_phase(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
-                     class_labels: Optional[torch.Tensor] = None, _ctx_kv=None, _x_batch: Optional[int] = None):
+                     class_labels: Optional[torch.Tensor] = None, _ctx_kv=None, _x_batch: Optional[int] = None,
+                     _tall=None):
         pk = self._pk or self._pack()
         if not x.is_cuda:
             raise CcnetError("ccnet_amd.DiffusionModelUNet runs on the GPU only (no CPU fallback)")
         x = x.contiguous().float()
         B = _x_batch or x.shape[0]
-        tall = self._embedding(pk, timesteps, class_labels, B)
+        tall = _tall if _tall is not None else self._embedding(pk, timesteps, class_labels, B)
         kvs, S = self.context_kv(context) if _ctx_kv is None else _ctx_kv
         c0 = self.block_out_channels[0]
         w, b = pk["conv_in"]
@@ -658,7 +688,7 @@ class ControlNet(_Trunk):
     @torch.no_grad()
     def forward_native(self, x, timesteps, controlnet_cond, conditioning_scale: float = 1.0, context=None,
                        class_labels=None, _ctx_kv=None, _cond_emb: Optional[Act] = None,
-                       _x_batch: Optional[int] = None, _unet_state=None, _before_zero=None):
+                       _x_batch: Optional[int] = None, _unet_state=None, _before_zero=None, _tall=None):
         """Same computation as forward(); returns the residuals as NHWC bf16 `Act`s.  With `_unet_state` (the result of
         DiffusionModelUNet.encode_phase on the same inputs) the zero-convolutions add the UNet's skips / middle output
         in their epilogue and the returned tensors are skip + residual, ready for decode_phase(); `_before_zero()` is
@@ -668,7 +698,7 @@ class ControlNet(_Trunk):
             raise CcnetError("ccnet_amd.ControlNet runs on the GPU only (no CPU fallback)")
         x = x.contiguous().float()
         B = _x_batch or x.shape[0]
-        tall = self._embedding(pk, timesteps, class_labels, B)
+        tall = _tall if _tall is not None else self._embedding(pk, timesteps, class_labels, B)
         if _ctx_kv is None:
             kvs, S = self.context_kv(context)
         else:

@@ -116,33 +116,46 @@ class Sampler:
             a = acquisition_time.reshape(B).float()
             cls = (torch.cat([a, a]) if self.cfg else a).reshape(-1, 1).to(cond.device)
         st["cls"] = cls
+        # every step's time-embedding projections in one batched evaluation per network ([T, Bc, channels]; None if too big)
+        tables = os.environ.get("CCNET_EMB_TABLE", "1") != "0"  # (switch for A/B timing)
+        st["tall_c"] = self.controlnet.embedding_table(self.scheduler.timesteps, cls, st["Bc"]) if tables else None
+        st["tall_u"] = self.diffusion.embedding_table(self.scheduler.timesteps, cls, st["Bc"]) if tables else None
         return st
 
-    def _model_output(self, st, x: torch.Tensor, ts: torch.Tensor) -> torch.Tensor:
-        """ControlNet + UNet on the latent x at timestep tensor ts -> model output fp32 [Bc, C, h, w]."""
+    def _model_output(self, st, x: torch.Tensor, ts: torch.Tensor, tall_c=None, tall_u=None) -> torch.Tensor:
+        """ControlNet + UNet on the latent x at timestep tensor ts -> model output fp32 [Bc, C, h, w].  tall_c / tall_u:
+        this step's rows of the embedding tables of prepare() (None: the networks evaluate their embedding MLPs)."""
         if not self.overlap or ops.prof_is_enabled():
             down, mid = self.controlnet.forward_native(
                 x, ts, None, self.conditioning_scale, class_labels=st["cls"], _ctx_kv=st["kv_c"],
-                _cond_emb=st["cond_emb"], _x_batch=st["Bc"])
+                _cond_emb=st["cond_emb"], _x_batch=st["Bc"], _tall=tall_c)
             return self.diffusion(x, ts, class_labels=st["cls"], down_block_additional_residuals=down,
-                                  mid_block_additional_residual=mid, _ctx_kv=st["kv_u"], _x_batch=st["Bc"])
+                                  mid_block_additional_residual=mid, _ctx_kv=st["kv_u"], _x_batch=st["Bc"], _tall=tall_u)
         cur = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=x.device)
         side = self._side
         side.wait_stream(cur)  # fork: everything the side stream touches was produced on `cur` (also inside a graph capture)
         with torch.cuda.stream(side):
-            enc = self.diffusion.encode_phase(x, ts, class_labels=st["cls"], _ctx_kv=st["kv_u"], _x_batch=st["Bc"])
+            enc = self.diffusion.encode_phase(x, ts, class_labels=st["cls"], _ctx_kv=st["kv_u"], _x_batch=st["Bc"],
+                                              _tall=tall_u)
         skips, mid = self.controlnet.forward_native(
             x, ts, None, self.conditioning_scale, class_labels=st["cls"], _ctx_kv=st["kv_c"],
-            _cond_emb=st["cond_emb"], _x_batch=st["Bc"], _unet_state=enc, _before_zero=lambda: cur.wait_stream(side))
+            _cond_emb=st["cond_emb"], _x_batch=st["Bc"], _unet_state=enc, _before_zero=lambda: cur.wait_stream(side),
+            _tall=tall_c)
         return self.diffusion.decode_phase(enc, skips, mid)
 
     @torch.no_grad()
-    def step(self, st, x: torch.Tensor, t, ddpm_noise: Optional[torch.Tensor] = None):
-        """One denoising step on the fp32 latent x (B,C,h,w); returns (x_prev, x0)."""
+    def step(self, st, x: torch.Tensor, t, ddpm_noise: Optional[torch.Tensor] = None, index: Optional[int] = None):
+        """One denoising step on the fp32 latent x (B,C,h,w); returns (x_prev, x0).  `index`: position of t in
+        scheduler.timesteps (selects the rows of prepare()'s embedding tables; looked up when omitted)."""
         ts = torch.tensor([float(t)], dtype=torch.float32, device=x.device)
-        out = self._model_output(st, x, ts)
+        tall_c = tall_u = None
+        if st.get("tall_c") is not None and st.get("tall_u") is not None:
+            if index is None:
+                index = [int(v) for v in self.scheduler.timesteps].index(int(t))
+            tall_c, tall_u = st["tall_c"][index], st["tall_u"][index]
+        out = self._model_output(st, x, ts, tall_c, tall_u)
         if self.cfg:
             if isinstance(self.scheduler, DDPMScheduler):
                 return self.scheduler.step_cfg(out, t, x, self.guidance_scale, noise=ddpm_noise)
@@ -155,7 +168,7 @@ class Sampler:
     def _static_step(self, g):
         """The step on static buffers: ControlNet -> UNet -> fused CFG + scheduler update of g["x"] in place."""
         st = g["st"]
-        out = self._model_output(st, g["x"], g["ts"])
+        out = self._model_output(st, g["x"], g["ts"], g["tall_c"], g["tall_u"])
         if self.cfg:
             mode, gs = _cfg_mode(self.guidance_scale)
         else:
@@ -186,6 +199,9 @@ class Sampler:
              "noise": torch.zeros_like(x) if ddpm else None,
              "ts_table": torch.tensor(ts_host, dtype=torch.float32, device=dev).reshape(-1, 1),
              "coef_table": torch.stack([self.scheduler.coef_tensor(int(t), dev) for t in self.scheduler.timesteps])}
+        tables = st.get("tall_c") is not None and st.get("tall_u") is not None
+        g["tall_c"] = st["tall_c"][0].clone() if tables else None  # this step's embedding rows (static buffers)
+        g["tall_u"] = st["tall_u"][0].clone() if tables else None
         g["ts"].copy_(g["ts_table"][0])
         g["coef"].copy_(g["coef_table"][0])
         self._static_step(g)  # eager once: weight packing, kernel attributes and allocator warm-up stay out of the graph
@@ -210,6 +226,9 @@ class Sampler:
                 break
             g["ts"].copy_(g["ts_table"][i])
             g["coef"].copy_(g["coef_table"][i])
+            if g["tall_c"] is not None:
+                g["tall_c"].copy_(st["tall_c"][i])
+                g["tall_u"].copy_(st["tall_u"][i])
             if ddpm:
                 if int(t) > 0:
                     n = ddpm_noise[i] if ddpm_noise is not None else torch.randn(x0.shape, dtype=torch.float32)
@@ -235,7 +254,7 @@ class Sampler:
             for i, t in enumerate(self.scheduler.timesteps):
                 if max_steps is not None and i >= max_steps:
                     break
-                x, _ = self.step(st, x, int(t), None if ddpm_noise is None else ddpm_noise[i])
+                x, _ = self.step(st, x, int(t), None if ddpm_noise is None else ddpm_noise[i], index=i)
                 if record_latents:
                     trace.append(x.clone())
         res = {"latent": x}
