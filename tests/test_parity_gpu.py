@@ -495,3 +495,23 @@ def test_overlapped_step_matches_sequential_step(cuda):
     print(f"overlap vs sequential latent max-abs {d:.3e}")
     assert d <= 0.15  # two bf16 evaluation orders, each held to 0.1 against the fp32 oracle by test_sampler_parity_tiny
     assert psnr(res["ov_graph"]["image"], res["seq"]["image"].cpu()) >= 40.0
+
+
+def test_two_phase_unet_and_embedding_table(cuda):
+    """encode_phase + decode_phase is forward() cut in two (bit-identical without residuals), and a row of
+    embedding_table() is what the per-step embedding MLPs produce for that timestep (fp32 summation order aside)."""
+    pu, _ = build_pair("unet", TINY, 51, cuda, acq=True)
+    x, ctx, _ = _inputs(2, cuda, seed=52)
+    xg, cg = x.to(cuda), ctx.to(cuda)
+    cls = torch.tensor([[250.0], [700.0]]).to(cuda)
+    t = torch.tensor([500]).to(cuda)
+    ref = pu(xg, t, cg, cls)
+    st = pu.encode_phase(xg, t, cg, cls)
+    assert torch.equal(pu.decode_phase(st), ref)
+    table = pu.embedding_table([980, 500, 20], cls, 2)
+    assert table.shape[:2] == (3, 2)
+    per_step = pu._embedding(pu._pk or pu._pack(), t, cls, 2)
+    assert (table[1] - per_step).abs().max().item() <= 1e-4 * per_step.abs().max().item()
+    out = pu(xg, t, cg, cls, _tall=table[1])
+    assert (out - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert pu.embedding_table(range(1000), cls, 2, max_bytes=1024) is None  # too big: the caller falls back to per-step
