@@ -225,9 +225,12 @@ def main():
         ms, flops, launches = ops.prof_collect()
         ops.prof_enable(False)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = hbm_traffic_per_launch()
         roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": (traffic or {}).get("bytes_per_launch"),
+                "traffic_unit": "HBM bytes per launch (PMC passes, gfx950-corrected)",
+                "traffic_source": (traffic or {}).get("source"),
                 "launches": int(launches), "kernel_ms_total": round(ms, 3),
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                 "measured": "eager pass over one batch after the timed region, HIP events around every launch, the "
