@@ -52,6 +52,7 @@ SHAPES = [
     ("L0 ff1+GEGLU 320->2560 @64", 32, 64, 320, 0, 2560, 1, 1, 1, False, 2),
     ("L1 ff1+GEGLU 640->5120 @32", 32, 32, 640, 0, 5120, 1, 1, 1, False, 2),
     ("L2 ff1+GEGLU 1280->10240 @16", 32, 16, 1280, 0, 10240, 1, 1, 1, False, 2),
+    ("mid ff1+GEGLU 1280->10240 @8", 32, 8, 1280, 0, 10240, 1, 1, 1, False, 2),
     ("VAE conv3x3 128->128 @512 N=4", 4, 512, 128, 0, 128, 3, 1, 1),
     ("VAE conv3x3 256->256 @256 N=8", 8, 256, 256, 0, 256, 3, 1, 1),
 ]
