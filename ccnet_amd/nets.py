@@ -672,13 +672,19 @@ class ControlNet(_Trunk):
         pk["zero_mid"] = pconv(self.controlnet_mid_block)
 
     @torch.no_grad()
-    def cond_embedding(self, controlnet_cond: torch.Tensor) -> Act:
+    def cond_embedding(self, controlnet_cond: torch.Tensor, _max_bytes: int = 2 ** 31 - 1) -> Act:
         """controlnet_cond_embedding(cond): step-invariant, so a sampler computes it once per image."""
         pk = self._pk or self._pack()
         c = controlnet_cond.contiguous().float()
         if not c.is_cuda:
             raise CcnetError("ccnet_amd.ControlNet runs on the GPU only (no CPU fallback)")
         e0 = self.cond_channels[0]
+        # the first activations live at the conditioning image's resolution: keep each below the conv kernel's 2 GiB limit
+        per_image = c.shape[2] * c.shape[3] * max(_pad64(ch) for ch in self.cond_channels) * 2
+        chunk = max(1, _max_bytes // per_image)
+        if c.shape[0] > chunk:
+            parts = [self.cond_embedding(c[i:i + chunk], _max_bytes) for i in range(0, c.shape[0], chunk)]
+            return Act(torch.cat([p_.t for p_ in parts]), c.shape[0], parts[0].H, parts[0].W, parts[0].C)
         h = ops.conv_in_small(c, c.shape[0], pk["ce_in"][0], pk["ce_in"][1], e0, _pad64(e0), act=1)
         for w, b, stride, cop in pk["ce_blocks"]:
             h = ops.conv(h, w, b, cop, R=3, stride=stride, act=1)

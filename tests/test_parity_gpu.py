@@ -515,3 +515,15 @@ def test_two_phase_unet_and_embedding_table(cuda):
     out = pu(xg, t, cg, cls, _tall=table[1])
     assert (out - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
     assert pu.embedding_table(range(1000), cls, 2, max_bytes=1024) is None  # too big: the caller falls back to per-step
+
+
+def test_cond_embedding_chunks_over_images(cuda):
+    """Batches whose 512^2-resolution activations would pass the conv kernel's 2 GiB tensor limit are embedded in chunks of
+    images; the result is the unchunked one."""
+    pc, _ = build_pair("controlnet", {**TINY, **TINY_CE}, 61, cuda)
+    _, _, cond = _inputs(5, cuda, seed=62)
+    whole = pc.cond_embedding(cond.to(cuda))
+    per_image = 128 * 128 * 256 * 2
+    parts = pc.cond_embedding(cond.to(cuda), _max_bytes=2 * per_image)  # two images per chunk: 2 + 2 + 1
+    assert (parts.N, parts.H, parts.W, parts.C) == (whole.N, whole.H, whole.W, whole.C)
+    assert torch.equal(parts.t, whole.t)
