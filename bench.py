@@ -107,10 +107,44 @@ def hbm_traffic_per_launch():
     return None
 
 
+def launch_ranks(n: int) -> int:
+    """Parent of an N > 1 run started as plain `python bench.py --gpus N ...`: spawn
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` as a CHILD process (never an exec: see the environment notes on processes that have touched the GPU; this
+    one has not, and stays off it), pass the children's stderr through, print the one JSON line rank 0 produced and return
+    the launcher's exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed batches per rank (default 2; 8 when --gpus > 1: 8 GPUs x 8 batches x 16 = the 1024 slices of "
+                         "BASELINE.json configs[2])")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--ddim-steps", type=int, default=50)
@@ -124,6 +158,13 @@ def main():
                     help="process-group backend; 'gloo' + fewer GPUs than ranks = a rehearsal of the N > 1 code path with "
                          "several ranks sharing a GPU (RCCL refuses that); its numbers mean nothing")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 8 if args.gpus > 1 else 2
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may invoke it: this process has made no GPU call yet and never will --
+        # it starts N fresh rank processes (one per GPU, torch.distributed.run) and relays rank 0's JSON line
+        sys.exit(launch_ranks(args.gpus))
 
     if os.environ.get("CCNET_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack if the run takes this many seconds
         import faulthandler
@@ -191,6 +232,7 @@ def main():
         return r["latent"], u8
 
     # timed region: the denoising step replays as a HIP graph (Sampler.use_graph), so no per-launch host work
+    gathered_shapes = None
     for k in range(args.warmup):
         one_pass(batches[k])
     torch.cuda.synchronize()
@@ -199,7 +241,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.warmup, nb):
-        one_pass(batches[k])
+        lat_all, img_all = one_pass(batches[k])
+    gathered_shapes = {"latent": list(lat_all.shape), "image_u8": list(img_all.shape)}  # [world * B, ...]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -253,7 +296,8 @@ def main():
                                    "geometry + acq-time MLP + stage1 AEKL decode; seeded random weights",
                        "batch_per_gpu": B, "ddim_steps": args.ddim_steps, "guidance_scale": 7.0,
                        "controlnet_unet_encoder_overlap": bool(sampler.overlap),
-                       "sharding": f"seed-indexed contiguous blocks over {world} rank(s), all_gather of latents+uint8"},
+                       "sharding": f"seed-indexed contiguous blocks over {world} rank(s), all_gather of latents+uint8",
+                       "gathered_shapes": gathered_shapes},
         }
         if roof is not None:
             out["roofline"] = roof

@@ -448,13 +448,19 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const __bf16* x, int 
     }
 }
 
-__global__ __launch_bounds__(256) void to_uint8_kernel(const float* x, int N, int C, int HW, uint8_t* out) {
+// Bit-exact with the reference's numpy recipe (util.py:1402-1414, 1162-1173): float64 throughout for the synthetic slice
+// (`.astype(np.float64)` -> (x - (-1)) / 2.0 -> 0 + s * 1 -> clip -> rint(s * 255), ties to even); f32_scale != 0 is the
+// form the comparison panels take (util.py:1432-1435): cond / images stay float32 numpy arrays through
+// (x - from_min) / from_range and only then become float64.  NaN maps to 0 (what the x86 uint8 cast of a NaN yields).
+__global__ __launch_bounds__(256) void to_uint8_kernel(const float* x, int N, int C, int HW, int f32_scale, uint8_t* out) {
     const long long total = (long long)N * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long n = i / HW, p = i % HW;
-        float v = (x[n * C * HW + p] + 1.0f) * 0.5f;
-        v = fminf(fmaxf(v, 0.f), 1.f);
-        out[i] = (uint8_t)rintf(v * 255.0f);
+        const float xv = x[n * C * HW + p];
+        double s = f32_scale ? (double)((xv - (-1.0f)) / 2.0f) : ((double)xv - (-1.0)) / 2.0;
+        s = 0.0 + s * 1.0;
+        s = fmin(fmax(s, 0.0), 1.0);
+        out[i] = (uint8_t)rint(s * 255.0);
     }
 }
 
@@ -553,7 +559,7 @@ extern "C" const char* ccnet_strerror(int code) {
         default: return "unknown error";
     }
 }
-extern "C" int ccnet_version(void) { return 2; }
+extern "C" int ccnet_version(void) { return 3; }
 extern "C" const char* ccnet_arch(void) { return "gfx950"; }
 
 extern "C" int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo, void* stream) {
@@ -695,10 +701,10 @@ extern "C" int ccnet_nhwc_bf16_to_nchw_f32(const void* x, int ldx, int N, int C,
     return CCNET_OK;
 }
 
-extern "C" int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* stream) {
+extern "C" int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t* out, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return CCNET_EINVAL;
     hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for((long long)N * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, N,
-                       C, HW, out);
+                       C, HW, f32_scale, out);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

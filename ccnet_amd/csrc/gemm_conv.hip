@@ -824,7 +824,9 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
         (void)hipEventRecord(rec->e0, st);
     }
     const bool geglu = p->act == 2;
-    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, true, &a.splitk);
+    // a caller that brings no workspace gets the best unsplit plan (slower on deep-K, few-tile problems, never an error);
+    // one that brings a workspace must bring what ccnet_conv_workspace_bytes() reports
+    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, p->workspace != nullptr, &a.splitk);
     if (a.splitk > 1) {
         if (!p->workspace || p->workspace_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return CCNET_EWS;
         a.ws = (float*)p->workspace;

@@ -33,11 +33,11 @@ def load_images(paths: Sequence[Union[str, Path]], img_height: int = 512, img_wi
     return torch.cat(out, dim=0)
 
 
-def _u8(x) -> np.ndarray:
+def _u8(x, f32_scale: bool = False) -> np.ndarray:
     x = getattr(x, "sample", x)  # diffusers DecoderOutput (util.py:1402)
     if not torch.is_tensor(x) or not x.is_cuda:
         raise CcnetError("save_controlnet_inference_sample expects GPU tensors (the uint8 mapping runs on the GPU)")
-    return ops.to_uint8(x.float()).cpu().numpy()
+    return ops.to_uint8(x.float(), f32_scale=f32_scale).cpu().numpy()
 
 
 def save_controlnet_inference_sample(run_dir, filename: Union[str, Sequence[str]], sample, cond=None, images=None,
@@ -56,7 +56,7 @@ def save_controlnet_inference_sample(run_dir, filename: Union[str, Sequence[str]
         Image.fromarray(s[i]).save(path)
         written.append(path)
     if save_comparison and cond is not None and images is not None:
-        c, r = _u8(cond), _u8(images)
+        c, r = _u8(cond, True), _u8(images, True)  # float32 arrays in the reference (util.py:1432-1435)
         (run_dir / "PIL_comparison").mkdir(parents=True, exist_ok=True)
         for i, nm in enumerate(names):
             path = run_dir / "PIL_comparison" / nm

@@ -83,7 +83,7 @@ def load() -> C.CDLL:
     lib.ccnet_cfg_scheduler_step.argtypes = [vp, i, f, vp, vp, vp, vp, i, i, vp]
     lib.ccnet_nchw_f32_to_nhwc_bf16.argtypes = [vp, i, i, i, vp, i, vp]
     lib.ccnet_nhwc_bf16_to_nchw_f32.argtypes = [vp, i, i, i, i, vp, vp]
-    lib.ccnet_to_uint8.argtypes = [vp, i, i, i, vp, vp]
+    lib.ccnet_to_uint8.argtypes = [vp, i, i, i, i, vp, vp]
     lib.ccnet_preprocess_u8_bicubic.argtypes = [vp, i, i, i, i, vp, i, i, vp]
     lib.ccnet_pointwise_nchw_f32.argtypes = [vp, i, i, i, vp, vp, i, i, vp, vp]
     lib.ccnet_axpy_f32.argtypes = [vp, vp, vp, C.c_longlong, vp, vp]

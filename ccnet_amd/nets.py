@@ -40,6 +40,17 @@ def _pad64(c: int) -> int:
     return (c + 63) // 64 * 64
 
 
+def _even_chunk(n: int, limit: int) -> int:
+    """Images per chunk when `n` images must be processed at most `limit` at a time: the fewest chunks, all (nearly) the same
+    size.  Sixteen images under a limit of 15 run as 8 + 8, not 15 + 1: a lone last image would be planned differently by
+    the conv dispatch (other tiles, split-K) and so round differently -- results must not depend on where in a batch an
+    image sits."""
+    if n <= limit:
+        return max(n, 1)
+    k = (n + limit - 1) // limit
+    return (n + k - 1) // k
+
+
 # --------------------------------------------------------------------------- parameter containers
 class _Holder(nn.Module):
     """Parameter container; deliberately has no forward."""
@@ -287,6 +298,7 @@ class _Trunk(nn.Module):
         pk["down"] = {id(b): pconv(b.downsampler.op.conv) for b in self.down_blocks if b.downsampler is not None}
         self._pack_extra(pk, pconv, f32)
         self._pk = pk
+        self._pk_gen = getattr(self, "_pk_gen", 0) + 1  # samplers key their captured graphs on it (sampling._graph_for)
         return pk
 
     def _pack_extra(self, pk, pconv, f32):
@@ -681,7 +693,7 @@ class ControlNet(_Trunk):
         e0 = self.cond_channels[0]
         # the first activations live at the conditioning image's resolution: keep each below the conv kernel's 2 GiB limit
         per_image = c.shape[2] * c.shape[3] * max(_pad64(ch) for ch in self.cond_channels) * 2
-        chunk = max(1, _max_bytes // per_image)
+        chunk = _even_chunk(c.shape[0], max(1, _max_bytes // per_image))
         if c.shape[0] > chunk:
             parts = [self.cond_embedding(c[i:i + chunk], _max_bytes) for i in range(0, c.shape[0], chunk)]
             return Act(torch.cat([p_.t for p_ in parts]), c.shape[0], parts[0].H, parts[0].W, parts[0].C)
@@ -958,7 +970,7 @@ class AutoencoderKL(nn.Module):
         z = z.contiguous().float()
         zq = ops.pointwise_nchw(z, pk["post_quant_conv"][0], pk["post_quant_conv"][1], 0)
         up = 2 ** (len(self.num_channels) - 1)
-        chunk = self._batch_chunk(z.shape[2] * up, z.shape[3] * up)
+        chunk = _even_chunk(z.shape[0], self._batch_chunk(z.shape[2] * up, z.shape[3] * up))
         if z.shape[0] <= chunk:
             return self._run(pk["decoder"], zq)
         return torch.cat([self._run(pk["decoder"], zq[i:i + chunk].contiguous())
@@ -975,7 +987,7 @@ class AutoencoderKL(nn.Module):
         if not x.is_cuda:
             raise CcnetError("ccnet_amd.AutoencoderKL runs on the GPU only (no CPU fallback)")
         x = x.contiguous().float()
-        chunk = self._batch_chunk(x.shape[2], x.shape[3])
+        chunk = _even_chunk(x.shape[0], self._batch_chunk(x.shape[2], x.shape[3]))
         if x.shape[0] <= chunk:
             h = self._run(pk["encoder"], x)
         else:

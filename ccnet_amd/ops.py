@@ -92,13 +92,20 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
         raise _l.CcnetError("res1 rows mismatch")
     if rowvec is not None and (rowvec.shape[0] != x.N or rowvec.shape[1] < Cout or rowvec.dtype != torch.float32):
         raise _l.CcnetError("rowvec must be fp32 [N, >=Cout]")
+    _launch_conv(p, x.t.device, "conv_gemm")
+    return (out, out2) if out2 is not None else out
+
+
+def _launch_conv(p, device, what: str) -> None:
+    """ccnet_conv_gemm_bf16 with the split-K workspace the library asks for (every caller goes through here: a deep-K
+    problem with few tiles -- also a batch-1 P.V product of the generic attention path -- is planned with K slices)."""
+    lib = _l.load()
     wsb = lib.ccnet_conv_workspace_bytes(C.byref(p))
     ws = None
     if wsb:
-        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.t.device)  # split-K partial sums
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=device)  # split-K partial sums
         p.workspace = ws.data_ptr(); p.workspace_bytes = wsb
-    _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "conv_gemm")
-    return (out, out2) if out2 is not None else out
+    _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), what)
 
 
 def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int, batch: int,
@@ -111,7 +118,7 @@ def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn
     p.C1 = K; p.C2 = 0; p.Cout = Nn; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
     p.ldx1 = ldx; p.ldw = ldw; p.ldo = ldo; p.scale = 1.0; p.batch = batch
     p.sx1 = sx; p.sw = sw; p.so = so
-    _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "gemm_batched")
+    _launch_conv(p, x.device, "gemm_batched")
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, Cin: int,
@@ -244,7 +251,7 @@ def attention_generic(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int,
         p.C1 = d; p.C2 = 0; p.Cout = Sp; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
         p.ldx1 = qh.stride(0); p.ldw = d; p.ldo = Sp; p.scale = scale; p.batch = B
         p.sx1 = Sq * qh.stride(0); p.sw = Sp * d; p.so = Sq * Sp
-        _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "attention scores")
+        _launch_conv(p, dev, "attention scores")
         s2 = scores.view(B * Sq, Sp)
         _l.check(lib.ccnet_softmax_rows_bf16(s2.data_ptr(), Sp, B * Sq, Skv, Sp, 1.0, s2.data_ptr(), Sp, _stream()),
                  "softmax_rows")
@@ -255,7 +262,7 @@ def attention_generic(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int,
         p.C1 = Sp; p.C2 = 0; p.Cout = d; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
         p.ldx1 = Sp; p.ldw = Sp; p.ldo = o.stride(0); p.scale = 1.0; p.batch = B
         p.sx1 = Sq * Sp; p.sw = d * Sp; p.so = Sq * o.stride(0)
-        _l.check(lib.ccnet_conv_gemm_bf16(C.byref(p), _stream()), "attention P.V")
+        _launch_conv(p, dev, "attention P.V")
     return o
 
 
@@ -339,13 +346,15 @@ def act_to_nchw(a: Act, Cc: Optional[int] = None) -> torch.Tensor:
     return out
 
 
-def to_uint8(x: torch.Tensor) -> torch.Tensor:
+def to_uint8(x: torch.Tensor, f32_scale: bool = False) -> torch.Tensor:
+    """interval_mapping -> rint(* 255) -> uint8 of channel 0, bit-exact with the reference's numpy recipe: float64 for the
+    synthetic slice (util.py:1402-1414), `f32_scale=True` for the float32 (x + 1) / 2 of the comparison panels (:1432-1435)."""
     lib = _l.load()
     _need_cuda(x)
     N, Cc, H, W = x.shape
     x = x.contiguous().float()
     out = torch.empty((N, H, W), dtype=torch.uint8, device=x.device)
-    _l.check(lib.ccnet_to_uint8(x.data_ptr(), N, Cc, H * W, out.data_ptr(), _stream()), "to_uint8")
+    _l.check(lib.ccnet_to_uint8(x.data_ptr(), N, Cc, H * W, int(f32_scale), out.data_ptr(), _stream()), "to_uint8")
     return out
 
 

@@ -186,8 +186,20 @@ class Sampler:
             dst["cls"].copy_(src["cls"])
 
     def _graph_for(self, st, x: torch.Tensor, ddpm: bool):
+        # Everything the capture bakes into the graph is part of the key: kernel scalars (guidance / conditioning scale, CFG
+        # mode, the scheduler's prediction type and clipping live in `coef`, refreshed per step), the launch topology
+        # (cfg, overlap) and the device addresses of the packed weights.  A network re-packs after load_state_dict / .to() /
+        # adjust_class_embedding (new tensors, the old ones are freed): its pack generation then changes and every
+        # cached graph is dropped, so no replay can read freed weights.
+        gen = (getattr(self.controlnet, "_pk_gen", 0), getattr(self.diffusion, "_pk_gen", 0))
+        if gen != getattr(self, "_graph_gen", None):
+            self._graphs.clear()
+            self._graph_gen = gen
         key = (tuple(x.shape), st["Bc"], st["cls"] is None, st["kv_c"][1], ddpm, id(self.scheduler),
-               tuple(int(t) for t in self.scheduler.timesteps[:2]), len(self.scheduler.timesteps))
+               tuple(int(t) for t in self.scheduler.timesteps[:2]), len(self.scheduler.timesteps),
+               None if self.guidance_scale is None else float(self.guidance_scale), float(self.conditioning_scale),
+               bool(self.cfg), bool(self.overlap), st.get("tall_c") is not None,
+               getattr(self.scheduler, "clip_sample", None), getattr(self.scheduler, "prediction_type", None))
         g = self._graphs.get(key)
         if g is not None:
             self._copy_state(g["st"], st)
@@ -198,7 +210,8 @@ class Sampler:
              "coef": torch.zeros(8, dtype=torch.float32, device=dev),
              "noise": torch.zeros_like(x) if ddpm else None,
              "ts_table": torch.tensor(ts_host, dtype=torch.float32, device=dev).reshape(-1, 1),
-             "coef_table": torch.stack([self.scheduler.coef_tensor(int(t), dev) for t in self.scheduler.timesteps])}
+             "coef_table": torch.stack([self.scheduler.coef_tensor(int(t), dev) for t in self.scheduler.timesteps]),
+             "pk": (self.controlnet._pk, self.diffusion._pk)}  # the captured weight pointers stay alive with the graph
         tables = st.get("tall_c") is not None and st.get("tall_u") is not None
         g["tall_c"] = st["tall_c"][0].clone() if tables else None  # this step's embedding rows (static buffers)
         g["tall_u"] = st["tall_u"][0].clone() if tables else None

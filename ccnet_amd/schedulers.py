@@ -43,7 +43,7 @@ class Scheduler:
         raise NotImplementedError
 
     def coef_tensor(self, t: int, device) -> torch.Tensor:
-        key = (int(t), str(device))
+        key = (int(t), str(device), getattr(self, "clip_sample", None), getattr(self, "prediction_type", None))
         c = self._coef_cache.get(key)
         if c is None:
             c = torch.tensor(self._coef(int(t)), dtype=torch.float32).to(device)

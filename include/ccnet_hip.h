@@ -75,7 +75,8 @@ typedef struct ccnet_conv_params {
 
 int ccnet_conv_gemm_bf16(const ccnet_conv_params* p /*host*/, void* stream);
 /* Deep-K layers with few output tiles are split along K (partial sums in `workspace`, summed in slice order by a second
- * launch): bytes the caller must provide for this problem, 0 if it runs unsplit. */
+ * launch): bytes the caller must provide for this problem, 0 if it runs unsplit.  With workspace == NULL the problem runs
+ * unsplit (correct, slower where a split was planned); a non-NULL workspace smaller than this returns CCNET_EWS. */
 size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p /*host*/);
 
 /* Direct 3x3 convolution for tiny channel counts at the network edges.
@@ -157,7 +158,9 @@ int ccnet_linear_f32(const float* x, int ldx, int B, int K, const float* w, cons
 /* ------------------------------------------------------------------ K9
  * Classifier-free-guidance combine + scheduler step, fp32, one launch.
  *   model_out fp32 NCHW [2B or B][...]: uncond = first B images, text = last B (run_controlnet_inference.py:245).
- *   mode 0: pred=text (guidance None), 1: pred=uncond (guidance 0), 2: uncond + g*(text-uncond).
+ *   mode 0: pred=text (guidance None), 1: pred=uncond (guidance 0), 2: uncond + g*(text-uncond);
+ *   mode 3: model_out holds B images only and is the prediction itself (no CFG batch: the loop of
+ *           log_controlnet_samples, util.py:885-909).
  *   coef (device, 8 floats): {sqrt_acp_t, sqrt_1m_acp_t, c_x0, c_eps_or_xt, sigma, clip(0/1), pred_type(0 eps,1 sample,2 v), ddpm(0/1)}
  *   DDIM: prev = c_x0*x0 + c_eps*eps ; DDPM: prev = c_x0*x0 + c_xt*x + sigma*noise   (scheduler.step, :253)
  */
@@ -182,8 +185,12 @@ int ccnet_axpy_f32(const float* a, const float* b, const float* c, long long n, 
 int ccnet_preprocess_u8_bicubic(const uint8_t* src, int N, int H0, int W0, int transpose, float* out, int H, int W,
                                 void* stream);
 
-/* clip((x+1)/2,0,1) -> rint(*255) -> uint8 of channel 0 (util.py:1162-1173,1412-1416). x fp32 NCHW. */
-int ccnet_to_uint8(const float* x, int N, int C, int HW, uint8_t* out, void* stream);
+/* interval_mapping(x, -1, 1, 0, 1) -> rint(* 255) -> uint8 of channel 0 (util.py:1162-1173, 1412-1416). x fp32 NCHW.
+ * Integer output, so the arithmetic is the reference's, bit for bit: f32_scale = 0 is the synthetic slice's recipe
+ * (`.astype(np.float64)` first, util.py:1402-1414: everything in float64, rint = ties to even); f32_scale = 1 is what the
+ * comparison panels get (util.py:1432-1435: cond / images reach interval_mapping as float32 arrays, so (x + 1) / 2 is
+ * evaluated in float32 and only its result is widened).  NaN -> 0. */
+int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------ profiling hooks for bench.py
  * When enabled, ccnet_conv_gemm_bf16 brackets each launch with hipEvents on `stream`;

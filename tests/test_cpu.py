@@ -277,12 +277,13 @@ def _worker(rank, world, port, n_total, bs, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,bs", [(10, 3), (7, 4)])
+@pytest.mark.parametrize("n_total,bs", [(10, 3), (7, 4), (1, 4)])  # (1, 4): rank 1 owns nothing and still gathers
 def test_sharded_sampling_gloo_world2(n_total, bs):
     import torch.multiprocessing as mp
     from ccnet_amd.distributed import sample_sharded, shard_indices
     from ccnet_amd.synthetic import make_noise
     assert list(shard_indices(10, 4, 3)) == [9] and list(shard_indices(8, 8, 7)) == [7]
+    assert [len(shard_indices(9, 8, r)) for r in range(8)] == [2, 2, 2, 2, 1, 0, 0, 0]  # trailing ranks can be empty
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + n_total

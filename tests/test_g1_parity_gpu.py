@@ -1,0 +1,189 @@
+"""Parity at the REAL geometry (BASELINE.json configs[0], [1], [3], [4]) -- the north_star criterion measured where it is
+stated: SD-2.1-base geometry (G1) ControlNet + UNet, CFG, acquisition-time + text conditioning, stage1-YAML AEKL at 512^2.
+
+  (a) configs[0]/[1] arithmetic: batch 1, all 50 DDIM steps + AEKL decode through `Sampler` against `oracle.sampler.sample`
+      (the fp32 restatement of run_controlnet_inference.py:211-256; parity unpinned, see oracle/__init__.py): per-step latent
+      max-abs error for every one of the 50 steps, final-image PSNR >= 40 dB.
+  (b) configs[1]: batch 16 -- images are index-addressed: image i of the batched run equals the batch-1 run of index i
+      within bf16 tolerance, is independent of where in the batch it sits, and image 0 passes (a)'s bar against the oracle.
+  (c) configs[3] shape: AEKL stage1-YAML geometry ([128,256,256,512], configs/stage1/aekl_v0.yaml) decode and encode at
+      512^2 against the oracle.
+  (d) configs[4] arithmetic: DDPM (clip_sample=True, the default the reference inherits, run_controlnet_inference.py:112),
+      1000-step schedule, first 24 steps with injected ancestral noise, acquisition-time + text conditioning.
+
+The oracle runs on the host cores (~2 s per G1 CFG step on 16 cores): about 3 minutes for this file.
+Tolerances: per-step latent max-abs and PSNR as stated in each test (frozen from the first measured run).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from _common import G1, G1_CE, SCHED, build_pair, psnr, rel_l2
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+STAGE1 = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[128, 256, 256, 512], latent_channels=4,
+              num_res_blocks=2, attention_levels=[False] * 4, with_encoder_nonlocal_attn=False,
+              with_decoder_nonlocal_attn=False)
+GS, CS, SF = 7.0, 1.0, 0.1  # guidance scale, conditioning scale, latent scale factor (bench.py's configuration)
+# per-step latent max-abs tolerance for bf16 compute against the fp32 oracle on O(1) latents (|x| up to ~4.5)
+STEP_TOL = 0.1
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _report(name, obj):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, name), "w") as fh:
+            json.dump(obj, fh)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def g1(cuda):
+    pc, oc = build_pair("controlnet", {**G1, **G1_CE}, 101, cuda, acq=True)
+    pu, ou = build_pair("unet", G1, 102, cuda, acq=True)
+    pv, ov = build_pair("vae", STAGE1, 103, cuda)
+    return dict(pc=pc, oc=oc, pu=pu, ou=ou, pv=pv, ov=ov)
+
+
+def _sampler(g1, kind="ddim", steps=50, **kw):
+    import ccnet_amd.schedulers as ps
+    from ccnet_amd.sampling import Sampler
+    sch = ps.DDIMScheduler(clip_sample=False, **SCHED) if kind == "ddim" else ps.DDPMScheduler(**SCHED)
+    sch.set_timesteps(steps)
+    return Sampler(g1["pc"], g1["pu"], sch, g1["pv"], guidance_scale=GS, conditioning_scale=CS, scale_factor=SF, **kw)
+
+
+def _run(s, b, dev, **kw):
+    return s.sample(b["noise"].to(dev), b["cond"].to(dev), b["prompt_embeds"].to(dev), b["empty_prompt_embeds"].to(dev),
+                    b["acquisition_time"].to(dev), **kw)
+
+
+@pytest.fixture(scope="module")
+def oracle_b1(g1):
+    """configs[0]: the oracle's 50-step batch-1 run of index 0 (the CPU reference path), shared by (a) and (b)."""
+    import oracle.schedulers as osch
+    from ccnet_amd.synthetic import make_batch
+    from oracle.sampler import sample as osample
+    b = make_batch([0], seed=42, acq=True)
+    osc = osch.DDIMScheduler(clip_sample=False, **SCHED)
+    osc.set_timesteps(50)
+    ref = osample(g1["oc"], g1["ou"], osc, b["noise"], b["cond"], b["prompt_embeds"], b["empty_prompt_embeds"],
+                  guidance_scale=GS, conditioning_scale=CS, acquisition_time=b["acquisition_time"], stage1=g1["ov"],
+                  scale_factor=SF, record_latents=True)
+    return b, ref
+
+
+def test_g1_50_step_ddim_batch1_against_oracle(cuda, g1, oracle_b1):
+    b, ref = oracle_b1
+    res = _run(_sampler(g1), b, cuda, record_latents=True)
+    assert len(res["latents"]) == len(ref["latents"]) == 50
+    errs = [(a.cpu() - r).abs().max().item() for a, r in zip(res["latents"], ref["latents"])]
+    mags = [r.abs().max().item() for r in ref["latents"]]
+    db = psnr(res["image"], ref["image"])
+    from oracle.sampler import to_uint8 as o_u8
+    from ccnet_amd.sampling import to_uint8
+    du8 = (to_uint8(res["image"]).cpu().int() - torch.from_numpy(o_u8(ref["image"])).int()).abs()
+    print("G1 50-step per-step latent max-abs:", " ".join(f"{e:.3e}" for e in errs))
+    print(f"G1 50-step: max over steps {max(errs):.3e} (latent |max| {max(mags):.2f}), final latent rel-L2 "
+          f"{rel_l2(res['latent'], ref['latent']):.3e}, image PSNR {db:.2f} dB, uint8 mean |diff| {du8.float().mean():.3f} "
+          f"max {du8.max().item()}")
+    _report("r2_g1_parity_b1.json", {"per_step_max_abs": errs, "ref_latent_max": mags, "psnr_db": db,
+                                     "u8_mean_abs": du8.float().mean().item(), "u8_max_abs": int(du8.max())})
+    assert max(errs) <= STEP_TOL, f"per-step latent max-abs {max(errs):.3e} at step {errs.index(max(errs))}"
+    assert db >= 40.0
+
+
+def test_g1_batch16_is_index_addressed(cuda, g1, oracle_b1):
+    from ccnet_amd.synthetic import make_batch
+    idx = list(range(16))
+    s = _sampler(g1)
+    res = _run(s, make_batch(idx, seed=42, acq=True), cuda)
+    assert res["image"].shape == (16, 1, 512, 512) and res["latent"].shape == (16, 4, 64, 64)
+    assert torch.isfinite(res["image"]).all()
+    # image 0 of the batch against the oracle's batch-1 run of index 0
+    _, ref = oracle_b1
+    e0 = (res["latent"][:1].cpu() - ref["latent"]).abs().max().item()
+    db0 = psnr(res["image"][:1], ref["image"])
+    # batch-1 runs of a few indices on the HIP path: other tile configurations and split-K factors, same arithmetic
+    worst_l, worst_db = 0.0, 1e9
+    s1 = _sampler(g1)
+    for i in (0, 5, 15):
+        r1 = _run(s1, make_batch([i], seed=42, acq=True), cuda)
+        worst_l = max(worst_l, (r1["latent"] - res["latent"][i:i + 1]).abs().max().item())
+        worst_db = min(worst_db, psnr(r1["image"], res["image"][i:i + 1].cpu()))
+    # batch packing: the same 16 indices in another order give the same per-index results
+    perm = [7, 3, 15, 0, 9, 12, 1, 5, 14, 2, 11, 6, 13, 4, 10, 8]
+    rp = _run(s, make_batch(perm, seed=42, acq=True), cuda)
+    inv = torch.tensor([perm.index(i) for i in idx], device=res["latent"].device)
+    dperm = (rp["latent"][inv] - res["latent"]).abs().max().item()
+    print(f"G1 batch 16: image 0 vs oracle latent max-abs {e0:.3e}, PSNR {db0:.2f} dB; batch-16 vs batch-1 (indices 0, 5, 15) "
+          f"latent max-abs {worst_l:.3e}, worst PSNR {worst_db:.2f} dB; permuted batch latent max-abs {dperm:.3e}")
+    _report("r2_g1_parity_b16.json", {"img0_vs_oracle_latent_max_abs": e0, "img0_vs_oracle_psnr_db": db0,
+                                      "b16_vs_b1_latent_max_abs": worst_l, "b16_vs_b1_worst_psnr_db": worst_db,
+                                      "permuted_latent_max_abs": dperm})
+    assert e0 <= STEP_TOL and db0 >= 40.0
+    assert worst_l <= STEP_TOL and worst_db >= 40.0
+    assert dperm == 0.0  # a row's arithmetic does not depend on its position in the batch
+
+
+def test_aekl_stage1_geometry_512(cuda, g1):
+    """configs[3] shape: stage1-YAML AEKL at 512^2, decode (the sampler's last stage) and encode."""
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(2, 4, 64, 64, generator=g)
+    x = torch.rand(2, 1, 512, 512, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref = g1["ov"].decode(z)
+        rmu, rsig = g1["ov"].encode(x)
+    img = g1["pv"].decode(z.to(cuda))
+    mu, sig = g1["pv"].encode(x.to(cuda))
+    out = {}
+    for nm, a, r in (("decode", img, ref), ("encode_mu", mu, rmu), ("encode_sigma", sig, rsig)):
+        rl = rel_l2(a, r)
+        mr = (a.float().cpu() - r).abs().max().item() / r.abs().max().item()
+        out[nm] = {"rel_l2": rl, "max_rel": mr}
+        print(f"AEKL stage1 @512 {nm}: shape {tuple(a.shape)} rel_l2 {rl:.3e} max_rel {mr:.3e}")
+        assert tuple(a.shape) == tuple(r.shape) and rl <= 2e-2 and mr <= 6e-2, (nm, rl, mr)
+    out["decode_psnr_db"] = psnr(img, ref, data_range=float(ref.max() - ref.min()))
+    _report("r2_aekl512_parity.json", out)
+    # the batch-64 path of configs[3] splits over images (2 GiB per activation tensor): the chunks are of equal size, so
+    # every image sees the same dispatch plan (bit-identical to decoding that chunk alone), and chunk sizes only change
+    # bf16 rounding (other tile shapes / split-K factors), not the result
+    from ccnet_amd.nets import _even_chunk
+    assert _even_chunk(64, g1["pv"]._batch_chunk(512, 512)) == 13 and _even_chunk(16, 15) == 8 and _even_chunk(15, 15) == 15
+    z4 = torch.randn(4, 4, 64, 64, generator=g).to(cuda)
+    whole = g1["pv"].decode(z4)
+    lim = g1["pv"]._batch_chunk
+    try:
+        g1["pv"]._batch_chunk = lambda H, W: 3   # limit 3 -> chunks of 2 + 2, not 3 + 1
+        parts = g1["pv"].decode(z4)
+    finally:
+        g1["pv"]._batch_chunk = lim
+    assert torch.equal(parts[:2], g1["pv"].decode(z4[:2])) and torch.equal(parts[2:], g1["pv"].decode(z4[2:]))
+    assert rel_l2(parts, whole.cpu()) <= 1e-2
+
+
+def test_g1_ddpm_clip_sample_injected_noise(cuda, g1):
+    """configs[4] arithmetic at G1: DDPMScheduler(**config) -> clip_sample=True, 1000 timesteps, ancestral noise passed in."""
+    import oracle.schedulers as osch
+    from ccnet_amd.synthetic import make_batch
+    from oracle.sampler import sample as osample
+    steps = 24
+    b = make_batch([3], seed=42, acq=True)
+    g = torch.Generator().manual_seed(99)
+    dn = [torch.randn(1, 4, 64, 64, generator=g) for _ in range(steps)]
+    s = _sampler(g1, "ddpm", 1000)
+    assert s.scheduler.clip_sample is True and len(s.scheduler.timesteps) == 1000
+    res = _run(s, b, cuda, ddpm_noise=[n.to(cuda) for n in dn], record_latents=True, max_steps=steps, decode=False)
+    osc = osch.DDPMScheduler(**SCHED)
+    ref = osample(g1["oc"], g1["ou"], osc, b["noise"], b["cond"], b["prompt_embeds"], b["empty_prompt_embeds"],
+                  guidance_scale=GS, conditioning_scale=CS, acquisition_time=b["acquisition_time"], ddpm_noise=dn,
+                  record_latents=True, max_steps=steps)
+    errs = [(a.cpu() - r).abs().max().item() for a, r in zip(res["latents"], ref["latents"])]
+    print(f"G1 DDPM (clip_sample) {steps} steps per-step latent max-abs:", " ".join(f"{e:.3e}" for e in errs))
+    _report("r2_g1_parity_ddpm.json", {"per_step_max_abs": errs})
+    assert len(errs) == steps and max(errs) <= STEP_TOL

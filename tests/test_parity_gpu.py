@@ -325,6 +325,22 @@ def test_vae_attention_blocks_and_sd_vae_dialect(cuda):
     assert torch.allclose(post.logvar, 2 * torch.log(post.std))
 
 
+def test_aekl_attention_single_image_64x64_latent(cuda):
+    """One image through an AEKL whose non-local attention runs over 64 x 64 = 4096 tokens of 128 channels (monai-generative
+    with_decoder_nonlocal_attn, and the shape of diffusers' SD-VAE mid block on a single 512^2 slice): batch 1 makes the
+    generic attention path's GEMMs eligible for split-K, which needs the workspace at every call site."""
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[64, 128], latent_channels=4,
+               num_res_blocks=1, attention_levels=[False, False], with_encoder_nonlocal_attn=False,
+               with_decoder_nonlocal_attn=True)
+    p, o = build_pair("vae", cfg, 45, cuda)
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(46))
+    with torch.no_grad():
+        ref = o.decode(z)
+    out = p.decode(z.to(cuda))
+    assert out.shape == (1, 1, 128, 128)
+    _check(out, ref, "AEKL decode, 4096-token attention, one image")
+
+
 def test_sampler_on_the_diffusers_surface(cuda):
     """run_controlnet_inference.py:211-256 with the classes the reference's SD-2.1 path builds: UNet2DConditionModel,
     ControlNetModel.from_unet, diffusers AutoencoderKL (decode returns `.sample`), DDIM, CFG, acquisition times."""

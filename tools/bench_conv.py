@@ -54,6 +54,9 @@ SHAPES = [
     ("L1 ff1+GEGLU 640->5120 @32", 32, 32, 640, 0, 5120, 1, 1, 1, False, 2),
     ("L2 ff1+GEGLU 1280->10240 @16", 32, 16, 1280, 0, 10240, 1, 1, 1, False, 2),
     ("mid ff1+GEGLU 1280->10240 @8", 32, 8, 1280, 0, 10240, 1, 1, 1, False, 2),
+    ("X960 conv3x3 960->960 @32", 32, 32, 960, 0, 960, 3, 1, 1),      # Cout divisible by 192 and 320 (tile experiments)
+    ("X960 1x1 960->960 @64", 32, 64, 960, 0, 960, 1, 1, 1),
+    ("X768 conv3x3 768->768 @32", 24, 32, 768, 0, 768, 3, 1, 1),      # M = 24576 = 96 * 256 = 128 * 192, Cout = 3 * 256 = 4 * 192
     ("VAE conv3x3 128->128 @512 N=4", 4, 512, 128, 0, 128, 3, 1, 1),
     ("VAE conv3x3 256->256 @256 N=8", 8, 256, 256, 0, 256, 3, 1, 1),
 ]
