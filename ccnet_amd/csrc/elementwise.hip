@@ -556,6 +556,9 @@ extern "C" const char* ccnet_strerror(int code) {
         case CCNET_EUNSUP: return "unsupported configuration";
         case CCNET_ELAUNCH: return "HIP launch failed";
         case CCNET_EWS: return "workspace too small";
+        case CCNET_ESCRATCH:
+            return "split-K partial sums exceed the static scratch of ccnet_conv_gemm_bf16_noalloc (CCNET_NOALLOC_SCRATCH_BYTES): "
+                   "use ccnet_conv_gemm_bf16 with a caller workspace";
         default: return "unknown error";
     }
 }

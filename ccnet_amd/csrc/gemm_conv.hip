@@ -18,6 +18,7 @@
 // Epilogue: accumulators go through a per-wave fp32 LDS patch so that bias / time-embedding / residual
 // reads and the bf16 stores are 16 B per lane and contiguous per pixel row.
 #include "common.h"
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -761,7 +762,10 @@ extern "C" size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p) {
     return S > 1 ? (size_t)S * M * p->Cout * sizeof(float) : 0;
 }
 
-extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
+namespace {
+// Shared body of ccnet_conv_gemm_bf16 (workspace from the caller, `ws_limit_code` = CCNET_EWS) and of
+// ccnet_conv_gemm_bf16_noalloc (workspace = the library's static device array, no profiling records: those create events).
+int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int ws_limit_code, bool allow_prof, void* stream) {
     if (!p || !p->x1 || !p->w || !p->out) return CCNET_EINVAL;
     if (p->R != 1 && p->R != 3) return CCNET_EUNSUP;
     if (p->ups != 1 && p->ups != 2) return CCNET_EUNSUP;
@@ -810,7 +814,7 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
 
     hipStream_t st = (hipStream_t)stream;
     ProfRec* rec = nullptr;
-    if (g_prof_on) {
+    if (g_prof_on && allow_prof) {
         if (g_prof_used == g_prof.size()) {
             ProfRec r{};
             if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return CCNET_ELAUNCH;
@@ -826,13 +830,54 @@ extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
     const bool geglu = p->act == 2;
     // a caller that brings no workspace gets the best unsplit plan (slower on deep-K, few-tile problems, never an error);
     // one that brings a workspace must bring what ccnet_conv_workspace_bytes() reports
-    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, p->workspace != nullptr, &a.splitk);
+    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, ws != nullptr, &a.splitk);
     if (a.splitk > 1) {
-        if (!p->workspace || p->workspace_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return CCNET_EWS;
-        a.ws = (float*)p->workspace;
+        if (!ws || ws_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return ws_limit_code;
+        a.ws = (float*)ws;
     }
     const TileCfg& cfg = kCfgs[cfg_i];
     const int rc = a.splitk > 1 ? cfg.fn_split(a, batch, st) : geglu ? cfg.fn_geglu(a, batch, st) : cfg.fn(a, batch, st);
     if (rec) (void)hipEventRecord(rec->e1, st);
     return rc;
+}
+}  // namespace
+
+extern "C" int ccnet_conv_gemm_bf16(const ccnet_conv_params* p, void* stream) {
+    return conv_gemm_impl(p, p ? p->workspace : nullptr, p ? p->workspace_bytes : 0, CCNET_EWS, true, stream);
+}
+
+// ---------------------------------------------------------------- allocation-free entry point
+// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it):
+// ccnet_conv_gemm_bf16 with the split-K partial sums in a static device array instead of a caller workspace.  Every GPU
+// the library runs on holds its own copy of the array (CCNET_NOALLOC_SCRATCH_BYTES, until the process ends) at its own
+// address; host code never uses the array's NAME as an address (that is a host-side stand-in): the device address is
+// looked up once per device with hipGetSymbolAddress, with that device current, and kept.
+static __device__ __align__(256) unsigned char scratch[CCNET_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+int scratch_for_current_device(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return CCNET_ELAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return CCNET_ELAUNCH;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return CCNET_OK;
+}
+}  // namespace
+
+extern "C" int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p, void* stream) {
+    void* ws = nullptr;
+    const int rc = scratch_for_current_device(&ws);
+    if (rc != CCNET_OK) return rc;
+    // Nothing in the array has to start at zero: every K slice writes its whole [M][Cout] slab before the reduce pass
+    // reads it, so the previous call's contents are dead.  Calls that overlap on one GPU share the array and race.
+    return conv_gemm_impl(p, ws, (int64_t)CCNET_NOALLOC_SCRATCH_BYTES, CCNET_ESCRATCH, false, stream);
 }

@@ -21,7 +21,7 @@ EXPORTS = [
     "ccnet_linear_f32", "ccnet_cfg_scheduler_step", "ccnet_nchw_f32_to_nhwc_bf16", "ccnet_nhwc_bf16_to_nchw_f32",
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
     "ccnet_set_option", "ccnet_prof_shapes", "ccnet_conv_workspace_bytes", "ccnet_transpose_pad_bf16",
-    "ccnet_attention_d64_causal_bf16", "ccnet_embed_tokens_bf16", "ccnet_gelu_bf16",
+    "ccnet_attention_d64_causal_bf16", "ccnet_embed_tokens_bf16", "ccnet_gelu_bf16", "ccnet_conv_gemm_bf16_noalloc",
 ]
 
 
@@ -63,6 +63,7 @@ def load() -> C.CDLL:
     lib.ccnet_version.restype = i
     lib.ccnet_arch.restype = C.c_char_p
     lib.ccnet_conv_gemm_bf16.argtypes = [C.POINTER(ConvParams), vp]
+    lib.ccnet_conv_gemm_bf16_noalloc.argtypes = [C.POINTER(ConvParams), vp]
     lib.ccnet_conv_workspace_bytes.argtypes = [C.POINTER(ConvParams)]
     lib.ccnet_conv_workspace_bytes.restype = sz
     lib.ccnet_conv_in_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, vp, i, i, vp, i, i, i, vp]

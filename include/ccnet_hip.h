@@ -30,6 +30,7 @@ extern "C" {
 #define CCNET_EUNSUP (-2)   /* configuration the kernels do not cover        */
 #define CCNET_ELAUNCH (-3)  /* hipLaunch failed (see hipGetLastError)        */
 #define CCNET_EWS (-4)      /* workspace too small                           */
+#define CCNET_ESCRATCH (-5) /* ccnet_conv_gemm_bf16_noalloc: the problem's split-K partial sums exceed the static scratch */
 
 const char* ccnet_strerror(int code);
 int ccnet_version(void);          /* ABI version, bumped on any struct change */
@@ -78,6 +79,16 @@ int ccnet_conv_gemm_bf16(const ccnet_conv_params* p /*host*/, void* stream);
  * launch): bytes the caller must provide for this problem, 0 if it runs unsplit.  With workspace == NULL the problem runs
  * unsplit (correct, slower where a split was planned); a non-NULL workspace smaller than this returns CCNET_EWS. */
 size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p /*host*/);
+
+/* Allocation-free variant of ccnet_conv_gemm_bf16.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * arguments and results (bit-identical); p->workspace / p->workspace_bytes are ignored: the split-K partial sums live in
+ * a static device array of CCNET_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
+ * A problem whose plan needs more than that returns CCNET_ESCRATCH (ccnet_conv_workspace_bytes(p) tells beforehand).
+ * Calls no hipMalloc / hipFree / allocating routine; its first call on a device looks the array's address up once.
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams) race -- serialise them. */
+#define CCNET_NOALLOC_SCRATCH_BYTES (96u << 20) /* 96 MiB: SD-2.1 geometry up to 16 images per batch (CFG batch 32) */
+int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p /*host*/, void* stream);
 
 /* Direct 3x3 convolution for tiny channel counts at the network edges.
  *   conv_in_small : x fp32 NCHW [Nsrc][Cin<=8][H][W] (image n reads x[n % Nsrc]) -> NHWC bf16 [N][Hout][Wout][ldo]
