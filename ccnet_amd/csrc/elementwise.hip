@@ -655,7 +655,7 @@ extern "C" int ccnet_conv_in_small(const float* x, int Nsrc, int N, int Cin, int
 #undef CIS_ARGS
 }
 
-extern "C" int ccnet_conv_out_nchw(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, const float* bias,
+extern "C" __attribute__((visibility("hidden"))) int ccnet_conv_out_nchw(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, const float* bias,
                                    int Cout, float* out, void* stream);  // gemm_conv.hip
 
 extern "C" int ccnet_conv_out_small(const void* x, int ldx, int N, int H, int W, int Cin, const void* w,

@@ -7,17 +7,19 @@
 // v_mfma_f32_32x32x16_bf16 with the weights as the A operand (rows = cout) and the pixels as the B operand
 // (cols = pixel), so each lane ends up with 4 consecutive couts of one pixel per accumulator quad.
 //
-// K loop: one step = 64 channels of one tap.  Operand tiles go HBM/L2 -> LDS by LDS-DMA
+// K loop: one step = BK (64 or 32) channels of one tap.  Operand tiles go HBM/L2 -> LDS by LDS-DMA
 // (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write); the buffer range check returns 0 for the
 // padding taps and for rows beyond M / Cout, so the gather has no branches.  The LDS image of a tile is
-// [row][64] bf16 with the 16-B chunk index XOR-swizzled by ((row >> 1) & 7) -- applied on the SOURCE address,
+// [row][BK] bf16 with the 16-B chunk index XOR-swizzled by the row -- applied on the SOURCE address,
 // because a DMA lands at wave-base + lane*16 -- which makes the ds_read_b128 fragment reads conflict-free.
-// Two stages: the DMA of step k+1 is issued in four slices between the MFMA groups of step k and retired by
-// the vmcnt(0) + barrier that ends the step.
+// NS-stage ring (2..4 stages): the DMAs of steps k+1 .. k+NS-1 are in flight while step k's MFMAs run; a step
+// ends with a COUNTED s_waitcnt vmcnt(N) + raw s_barrier, so the newest NS-2 steps stay in flight across it.
+// Persistent instances walk tiles b, b + grid, ... and issue the next tile's first stages before their epilogue.
 //
-// Epilogue: accumulators go through a per-wave fp32 LDS patch so that bias / time-embedding / residual
-// reads and the bf16 stores are 16 B per lane and contiguous per pixel row.
+// Epilogue: straight from the accumulators (they start at bias + time-embedding row); v_permlane32_swap pairs
+// give each lane 8 consecutive couts of its pixel, i.e. one 16-B store / residual load per 16 columns.
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -529,9 +531,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------- profiling hooks
 struct ProfRec { hipEvent_t e0, e1; double flops; int M, Cout, K, R, flags; };
-bool g_prof_on = false;
+bool g_prof_on = false;       // benchmark hook (bench.py): while on, launches are serialised on g_prof_mu
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
+std::mutex g_prof_mu;
 
 int g_force_cfg = -1;  // tuning: force a tile configuration (index into the dispatch below)
 int g_force_splitk = 0;  // tuning: force the split-K factor (0 = heuristic)
@@ -548,12 +551,14 @@ template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, b
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // once per instantiation and process, safe under concurrent first calls from several host threads (the attribute is a
+    // property of the function, idempotent to set; the flag is only an optimisation)
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     ConvArgs b = a;
     b.CT1 = a.C1 / BK; b.CT = (a.C1 + a.C2) / BK; b.KT = a.R * a.R * b.CT;
@@ -737,7 +742,7 @@ extern "C" int ccnet_prof_shapes(double* table, int max_rows) {
 // Output convolution (3x3, stride 1, pad 1, Cin % 64 == 0, Cout <= 8) on the implicit-GEMM kernel: NHWC bf16 in, fp32 NCHW
 // out.  Called by ccnet_conv_out_small (elementwise.hip); w is [Cout][9][Cin] bf16 -- the rows a 32-cout tile reads
 // beyond Cout fall outside the weight descriptor and come back as zeros.
-extern "C" int ccnet_conv_out_nchw(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, const float* bias,
+extern "C" __attribute__((visibility("hidden"))) int ccnet_conv_out_nchw(const void* x, int ldx, int N, int H, int W, int Cin, const void* w, const float* bias,
                                    int Cout, float* out, void* stream) {
     if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 64) || (ldx % 8) || Cout <= 0 || Cout > 8)
         return CCNET_EINVAL;
@@ -814,7 +819,9 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
 
     hipStream_t st = (hipStream_t)stream;
     ProfRec* rec = nullptr;
+    std::unique_lock<std::mutex> prof_lock(g_prof_mu, std::defer_lock);
     if (g_prof_on && allow_prof) {
+        prof_lock.lock();  // the record vector is shared; with profiling off no lock is taken and calls are independent
         if (g_prof_used == g_prof.size()) {
             ProfRec r{};
             if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return CCNET_ELAUNCH;

@@ -14,7 +14,11 @@
  *   - every function enqueues on `stream` (a hipStream_t passed as void*), never
  *     synchronises, never allocates, and returns 0 or a negative CCNET_E* code
  *     (text via ccnet_strerror); nothing throws across the boundary;
- *   - the caller owns all memory, including workspaces (size queries provided).
+ *   - the caller owns all memory, including workspaces (size queries provided);
+ *   - compute entry points are re-entrant and may be called from several host threads on distinct streams; the
+ *     exceptions are the benchmark hooks at the end of this file (ccnet_set_option, ccnet_prof_*: process-wide state,
+ *     while profiling is enabled ccnet_conv_gemm_bf16 creates HIP events and serialises on a lock) and
+ *     ccnet_conv_gemm_bf16_noalloc (one scratch array per GPU: see its comment).
  */
 #ifndef CCNET_HIP_H
 #define CCNET_HIP_H
