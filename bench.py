@@ -92,6 +92,18 @@ def cpu_baseline(steps_sample: int, acq: bool):
                       f"({dec:.2f} s), extrapolated linearly to 50 steps; fp32 torch CPU ops"}
 
 
+def conv_algorithmic_bytes(M, Cout, K, R, flags):
+    """Bytes one conv / linear launch has to move if every operand crosses HBM exactly once: the input pixels (not the
+    im2col view), the weights, the output and the residual operands.  `flags` as in ccnet_prof_shapes: bit0 stride 2, bit1
+    nearest x2 upsample in the gather, bit3 GEGLU epilogue (output half as wide), bit4 res1, bit5 res2 + out2."""
+    fl = int(flags)
+    cin = K / (R * R)
+    in_pixels = M * (4 if fl & 1 else 1) / (4 if fl & 2 else 1)
+    cout_out = Cout / 2 if fl & 8 else Cout
+    n_out = 1 + (1 if fl & 16 else 0) + (2 if fl & 32 else 0)
+    return 2.0 * (in_pixels * cin + Cout * K + M * cout_out * n_out)
+
+
 def hbm_traffic_per_launch():
     """HBM bytes per conv_gemm launch from the committed PMC passes (profiles/*_hbm_traffic.csv, newest file):
     (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all instantiations -- bench.py cannot collect counters
@@ -258,22 +270,31 @@ def main():
         one_pass_local(batches[nb - 1])
         torch.cuda.synchronize()
         tp = time.perf_counter() - tp0
+        rows = sorted(ops.prof_shapes(2048), key=lambda r: -r[6])
+        alg_bytes = sum(conv_algorithmic_bytes(*r[:5]) * r[5] for r in rows)
         if args.shapes:
-            rows = sorted(ops.prof_shapes(), key=lambda r: -r[6])
             with open(args.shapes, "w") as fh:
-                fh.write("M Cout K R flags launches ms TFLOP/s\n")
+                fh.write("M Cout K R flags launches ms TFLOP/s algorithmic_MB_per_launch GB/s\n")
                 for M, Co, K, R, fl, n, ms_ in rows:
+                    ab = conv_algorithmic_bytes(M, Co, K, R, fl)
                     fh.write(f"{int(M)} {int(Co)} {int(K)} {int(R)} {int(fl)} {int(n)} {ms_:.3f} "
-                             f"{2.0 * M * Co * K * n / (ms_ * 1e9):.1f}\n")
+                             f"{2.0 * M * Co * K * n / (ms_ * 1e9):.1f} {ab / 2 ** 20:.1f} {ab * n / (ms_ * 1e6):.0f}\n")
         ms, flops, launches = ops.prof_collect()
         ops.prof_enable(False)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = hbm_traffic_per_launch()
+        alg_per_launch = alg_bytes / max(launches, 1)
+        tb = (traffic or {}).get("bytes_per_launch")
         roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": (traffic or {}).get("bytes_per_launch"),
-                "traffic_unit": "HBM bytes per launch (PMC passes, gfx950-corrected)",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tb,
+                "traffic_unit": "bytes per launch crossing the L2 -> fabric boundary (HBM + Infinity Cache), PMC passes "
+                                "FETCH_SIZE / WRITE_SIZE of this command, gfx950-corrected",
                 "traffic_source": (traffic or {}).get("source"),
+                # inputs once + weights once + outputs (+ residual operands), averaged over this pass's launches
+                "algorithmic_bytes": round(alg_per_launch),
+                "traffic_over_algorithmic": round(tb / alg_per_launch, 2) if tb else None,
+                "algorithmic_gbps": round(alg_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                 "launches": int(launches), "kernel_ms_total": round(ms, 3),
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
                 "measured": "eager pass over one batch after the timed region, HIP events around every launch, the "

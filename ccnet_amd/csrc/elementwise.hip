@@ -562,7 +562,7 @@ extern "C" const char* ccnet_strerror(int code) {
         default: return "unknown error";
     }
 }
-extern "C" int ccnet_version(void) { return 3; }
+extern "C" int ccnet_version(void) { return 4; }
 extern "C" const char* ccnet_arch(void) { return "gfx950"; }
 
 extern "C" int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo, void* stream) {

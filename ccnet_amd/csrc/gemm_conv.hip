@@ -31,7 +31,10 @@ namespace {
 #define STAMP(k)                                                                      \
     do {                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                            \
-        if (a.dbg && threadIdx.x == 0) a.dbg[(long long)stamp_slot * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (a.dbg && threadIdx.x == 0) {                                               \
+            a.dbg[(long long)stamp_slot * 8 + (k)] = __builtin_amdgcn_s_memtime();        \
+            if ((k) == 2 || (k) == 3) a.dbg[(long long)stamp_slot * 8 + 3 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
 #else
@@ -47,6 +50,7 @@ struct ConvArgs {
     float scale;
     int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
     long long sx1, sw, so;
+    const float* rowstat; const float* colsum;  // LayerNorm folded into the GEMM (see the accumulator start)
     float* out32; int cout_real;  // SPLIT instances only: != nullptr -> final fp32 NCHW output (+ bias), Cout <= 8 edge convs
     int splitk;   // > 1: blockIdx.y selects a K slice, raw fp32 partial sums go to ws[slice][M][Cout]
     float* ws;
@@ -70,9 +74,16 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wa
 // PERSIST = true: the grid is at most one block per CU slot and each block walks tiles b, b + grid, b + 2 grid, ...;
 // the next tile's first NS-1 stages are issued BEFORE the current tile's epilogue, so a short-K layer's tile start-up
 // (address set-up, HBM/L2 latency of the first stages) hides under the previous tile's stores.
-template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK, bool SPLIT, bool PERSIST>
+// RESPRE = true: the residual (res1) tile is fetched into registers at the START of the tile's K loop instead of inside the
+// epilogue.  A short-K layer with a residual is two phases that every CU runs in lockstep -- an MFMA-bound K loop during
+// which HBM idles, then an epilogue that moves the tile's residual + output at the per-CU streaming rate (~10 B/clk/CU:
+// 26k of the 35k epilogue cycles of a 256x320 tile, stamps in profiles/r02_stamp_clock.txt) -- so the memory time adds to the
+// MFMA time.  Prefetching spreads the residual read over the K loop; the prefetched tile does not fit L2 (164 KB per CU x
+// 32 CUs per XCD > 4 MB), so registers are the only place, and only the 80-accumulator 128x320 tile has 40 to spare.
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK, bool SPLIT, bool PERSIST, bool RESPRE = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs a) {
     static_assert(!(SPLIT && PERSIST), "split-K launches are never persistent");
+    static_assert(!RESPRE || (!SPLIT && !GEGLU), "residual prefetch: plain epilogue only");
     constexpr int NT = 64 * WM * WN, BM = 32 * TJ * WM, BN = 32 * TI * WN;
     static_assert(BK == 64 || BK == 32, "K-step of 64 or 32 channels");
     constexpr int CPW = BK / 8;            // 16-B chunks per tile row
@@ -221,18 +232,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     // Accumulators start at bias[cout] (+ the image's time-embedding row): register (i, j, 4q + e) of a lane is cout
     // n0 + wn*32*TI + 32 i + 8 q + 4 hh + e of pixel m0 + wm*32*TJ + 32 j + l31, so the epilogue has no column-indexed
     // operand left and these loads (issued after the first stages' DMAs) complete under the first tile's DMA latency.
+    // LayerNorm prologue, folded (a.rowstat != nullptr): x is the UN-normalised row matrix, w = gamma o W and
+    // bias = bias + W beta (packed so by the host), colsum[n] = sum_k w[n][k], rowstat[m] = (mean, rstd) of row m.
+    // LN(x) W^T + b = rstd_m (sum_k x_mk w_nk - mean_m colsum_n) + bias_n, so the accumulators start at
+    // bias_n / rstd_m - mean_m colsum_n and are scaled by rstd_m after the K loop: the normalised activations are never
+    // written to, or re-read from, HBM.  Without it (sigma = 1, mean = 0) the start is bias_n as before.
+    float ln_rstd[TJ], ln_sigma[TJ], ln_mean[TJ];
+    const bool ln = !SPLIT && a.rowstat != nullptr;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
+        f32x2 st = {0.f, 1.f};
+        if (ln) st = *(const f32x2*)(a.rowstat + 2ll * (m < a.M ? m : a.M - 1));
+        ln_mean[j] = st[0];
+        ln_rstd[j] = st[1];
+        ln_sigma[j] = ln ? 1.0f / st[1] : 1.0f;
+    }
     f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int nb = cn0 + wn * 32 * TI + i * 32 + 8 * q + 4 * hh;
-            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
             if (!SPLIT && a.bias && nb < a.Cout) bq = *(const f32x4*)(a.bias + nb);  // split-K: added by the reduce pass
+            if (ln && nb < a.Cout) cs = *(const f32x4*)(a.colsum + nb);
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bq[e];
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = ln ? bq[e] * ln_sigma[j] - ln_mean[j] * cs[e] : bq[e];
         }
     if (!GEGLU && !SPLIT && a.rowvec) {  // (the host rejects act = 2 with a time-embedding row)
 #pragma unroll
@@ -252,6 +280,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                 }
             __builtin_amdgcn_sched_barrier(0);  // one pixel block's 4*TI loads in flight at a time
         }
+    }
+
+    // residual prefetch: the epilogue's layout (after the permlane32 swap a lane owns 8 consecutive couts of its pixel)
+    u32x4 rpre[RESPRE ? TJ : 1][RESPRE ? TI : 1][2];
+    if constexpr (RESPRE) {
+        const bool has1 = a.res1 != nullptr;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
+            const __bf16* r1row = a.res1 + (long long)m * a.ldres1;
+#pragma unroll
+            for (int ob = 0; ob < TI; ++ob)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int ncol = cn0 + wn * 32 * TI + 8 * hh + ob * 32 + 16 * p;
+                    rpre[j][ob][p] = (has1 && m < a.M && ncol < a.Cout) ? *(const u32x4*)(r1row + ncol) : u32x4{0u, 0u, 0u, 0u};
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // issued here, before the K loop; consumed after it
     }
 
     // (a later tile of a persistent block has the previous epilogue's stores in the same counter: drain it, its
@@ -364,6 +411,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     };
     // element-wise stages run in place over the accumulators, each under ONE wave-uniform branch with a straight-line
     // body (per-item branches inside the unrolled store loops make hipcc spill)
+    if (a.rowstat) {  // folded LayerNorm: the row's 1 / sigma
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i][j][k] *= ln_rstd[j];
+    }
     if constexpr (GEGLU) {
 #pragma unroll
         for (int ob = 0; ob < TIO; ++ob)
@@ -441,7 +496,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                     for (int p = 0; p < 2; ++p) {
                         const int ncol = ncol0 + (ob0 + oo) * 32 + 16 * p;
                         const bool ok = ob0 + oo < TIO && mok && ncol < cout_out;
-                        rr1[oo][p] = (ok && has1) ? *(const u32x4*)(r1row + ncol) : u32x4{0u, 0u, 0u, 0u};
+                        if constexpr (RESPRE) rr1[oo][p] = rpre[j][ob0 + oo < TIO ? ob0 + oo : 0][p];
+                        else rr1[oo][p] = (ok && has1) ? *(const u32x4*)(r1row + ncol) : u32x4{0u, 0u, 0u, 0u};
                         rr2[oo][p] = (ok && has2) ? *(const u32x4*)(r2row + ncol) : u32x4{0u, 0u, 0u, 0u};
                     }
 #pragma unroll
@@ -547,7 +603,8 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
-template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false, bool PERSIST = false>
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false, bool PERSIST = false,
+          bool RESPRE = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
@@ -555,7 +612,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     // property of the function, idempotent to set; the flag is only an optimisation)
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST>,
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST, RESPRE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set.store(true, std::memory_order_release);
@@ -570,7 +627,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     // start-up is a small share and the hardware's dynamic block placement balances ragged tiles better)
     const int kmax = GEGLU ? 1280 : 640;
     const int grid = PERSIST && g_persist && b.KT * BK <= (g_persist > 1 ? g_persist : kmax) && b.tiles > kNumCUs ? kNumCUs : b.tiles;
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST>), dim3(grid, SPLIT ? b.splitk : 1, batch),
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST, RESPRE>), dim3(grid, SPLIT ? b.splitk : 1, batch),
                        dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
     if (SPLIT && !b.out32) {
@@ -606,6 +663,8 @@ const TileCfg kCfgs[] = {
     {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>, nullptr},    // 26: 4 waves, 72 KB
     {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr, launch<2, 2, 2, 5, false, 2, 32, true>},  // 27: 4 waves, 57 KB
     {128, 128, launch<2, 2, 2, 2, false, 3, 32>, nullptr, nullptr},              // 28: 48 KB: three blocks per CU
+    {128, 320, launch<4, 2, 1, 5, false, 2, 64>, nullptr, nullptr},              // 29: 8 waves of 32 x 160, 114 KB
+    {128, 320, launch<4, 2, 1, 5, false, 2, 64, false, true, true>, nullptr, nullptr},  // 30: 29, persistent, residual prefetch
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // 256 pixels x 32 couts, 4 waves, two blocks per CU: the output convolutions (Cout <= 8); raw-accumulator epilogue
@@ -626,7 +685,7 @@ constexpr float kReduceUs = 3.14f, kReduceUsPerElem = 1.165e-6f;
 constexpr int kMaxSplit = 32, kMinSliceSteps = 13;  // every K slice keeps a real K loop
 
 // Returns the tile configuration and sets *S_out (1 = no split-K).  `can_split`: the caller can run a reduce pass.
-int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, int* S_out) {
+int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, int* S_out, bool res_only = false) {
     *S_out = 1;
     const bool forced = g_force_cfg >= 0 && g_force_cfg < kNumCfgs && (geglu ? kCfgs[g_force_cfg].fn_geglu : kCfgs[g_force_cfg].fn);
     auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * batch; };
@@ -650,6 +709,17 @@ int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, in
         // Layers with whole rounds of the largest tiles (measured in situ: persistent 256x320 / 256x256 tiles, 45-50 % DMA duty,
         // beat every smaller tile there; the L2 -> LDS path delivers ~64 B/clk/CU, so (BM+BN)*128 B / 64 per K step must stay
         // well under the MFMA time BM*BN/32 clk)
+        // 128x320 tiles (8 waves of 32 x 160; measured with tools/bench_conv.py --cold, profiles/r02_tile_experiments.log):
+        //  * K <= 320 with a residual and nothing else in the epilogue (attention o-proj, proj_out at the 64x64 level): the
+        //    layer is HBM-bound and its epilogue, not its K loop, sets the time -- persistent with the residual tile
+        //    prefetched at the start of the K loop (RESPRE): 391 vs 341 TFLOP/s;
+        //  * one round of them where 256x320 tiles would fill half the chip (M = 8192, Cout = K = 1280: 256 vs 128 tiles):
+        //    760-830 vs 646-750 TFLOP/s; deeper K goes back to the big tile, whose K loop is the more efficient one
+        if ((Cout % 320) == 0 && batch == 1) {
+            const long long t128 = tiles(128, 320);
+            if (res_only && KT <= 5 && t128 >= 512) return 30;
+            if (t128 > 128 && t128 <= 256 && tiles(256, 320) < 200 && KT <= 24 && KT >= 10) return 29;
+        }
         if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
         if ((Cout % 256) == 0 && (Cout % 320) != 0 && tiles(256, 256) >= 150) return Cout == 256 ? 10 : 20;
         if ((Cout % 128) == 0 && (Cout % 320) != 0 && tiles(256, 128) >= 200) return 15;
@@ -763,7 +833,7 @@ extern "C" size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p) {
     const int KT = p->R * p->R * ((p->C1 + p->C2) / 64);
     const int M = p->N * p->Hout * p->Wout;
     int S = 1;
-    (void)plan_conv(M, p->Cout, KT, p->batch > 1 ? p->batch : 1, p->act == 2, true, &S);
+    (void)plan_conv(M, p->Cout, KT, p->batch > 1 ? p->batch : 1, p->act == 2, !p->rowstat, &S, p->res1 && !p->out2);
     return S > 1 ? (size_t)S * M * p->Cout * sizeof(float) : 0;
 }
 
@@ -788,6 +858,8 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     if (p->act < 0 || p->act > 2) return CCNET_EINVAL;
     if (p->act == 2 && (p->Cout % 64)) return CCNET_EINVAL;
     if (p->act == 2 && p->rowvec) return CCNET_EUNSUP;  // GEGLU: interleaved 32-row a / gate blocks
+    if ((p->rowstat != nullptr) != (p->colsum != nullptr)) return CCNET_EINVAL;
+    if (p->rowstat && (p->R != 1 || p->C2 != 0 || p->rowvec || batch > 1 || p->stride != 1 || p->ups != 1)) return CCNET_EUNSUP;
     // every gathered tap must fall inside the (upsampled) input or be a padding tap: checked in-kernel by
     // coordinates; here make sure the implied geometry is self-consistent so no row can index past x1/x2.
     const long long Hl = (long long)p->Hin * p->ups, Wl = (long long)p->Win * p->ups;
@@ -797,6 +869,7 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     ConvArgs a{};
     a.x1 = (const __bf16*)p->x1; a.x2 = (const __bf16*)p->x2; a.w = (const __bf16*)p->w;
     a.bias = p->bias; a.rowvec = p->rowvec; a.res1 = (const __bf16*)p->res1; a.res2 = (const __bf16*)p->res2;
+    a.rowstat = p->rowstat; a.colsum = p->colsum;
     a.out = (__bf16*)p->out; a.out2 = (__bf16*)p->out2;
     a.N = p->N; a.Hin = p->Hin; a.Win = p->Win; a.Hout = p->Hout; a.Wout = p->Wout;
     a.C1 = p->C1; a.C2 = p->C2; a.Cout = p->Cout; a.R = p->R; a.stride = p->stride; a.pad = p->pad; a.ups = p->ups;
@@ -837,7 +910,8 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     const bool geglu = p->act == 2;
     // a caller that brings no workspace gets the best unsplit plan (slower on deep-K, few-tile problems, never an error);
     // one that brings a workspace must bring what ccnet_conv_workspace_bytes() reports
-    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, ws != nullptr, &a.splitk);
+    // (a folded LayerNorm is applied in the K-loop kernel's own epilogue: such a layer never splits along K)
+    const int cfg_i = plan_conv(a.M, p->Cout, a.KT, batch, geglu, ws != nullptr && !p->rowstat, &a.splitk, p->res1 && !p->out2);
     if (a.splitk > 1) {
         if (!ws || ws_bytes < (int64_t)((size_t)a.splitk * a.M * p->Cout * sizeof(float))) return ws_limit_code;
         a.ws = (float*)ws;

@@ -235,6 +235,54 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const __bf16* x, int ldx
     }
 }
 
+// Row statistics only (the LayerNorm whose normalisation is folded into the consuming GEMM, gemm_conv.hip): same loads and
+// two-pass mean / variance as layernorm_kernel, 8 bytes written per row instead of the normalised row.
+template <int NCH, int RW>
+__global__ __launch_bounds__(256) void row_stats_kernel(const __bf16* x, int ldx, int rows, int C, float eps, float* stats) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= rows) return;
+    const int cols = C / 8;
+    u32x4 raw[RW][NCH];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int col = lane + k * 64;
+            const int row = min(row0 + r, rows - 1);
+            raw[r][k] = col < cols ? *(const u32x4*)(x + (long long)row * ldx + col * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    const float invC = 1.0f / (float)C;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float f[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            unpack8(raw[r][k], f[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[k][e];
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (lane + k * 64 < cols) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        if (lane == 0 && row0 + r < rows) *(f32x2*)(stats + 2ll * (row0 + r)) = f32x2{mean, rstd};
+    }
+}
+
+template <int NCH, int RW>
+void launch_row_stats(const __bf16* x, int ldx, int rows, int C, float eps, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL((row_stats_kernel<NCH, RW>), dim3((rows + 4 * RW - 1) / (4 * RW)), dim3(256), 0, st, x, ldx, rows, C,
+                       eps, stats);
+}
+
 template <int NCH, int RW>
 void launch_layernorm(const __bf16* x, int ldx, int rows, int C, float eps, const float* gamma, const float* beta,
                       __bf16* out, int ldo, hipStream_t st) {
@@ -405,6 +453,21 @@ extern "C" int ccnet_layernorm_bf16(const void* x, int ldx, int rows, int C, flo
     else if (nch == 2) launch_layernorm<2, 4>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
     else if (nch == 3) launch_layernorm<3, 2>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
     else launch_layernorm<4, 2>(xp, ldx, rows, C, eps, gamma, beta, op, ldo, st);
+    CCNET_LAUNCH_CHECK();
+    return CCNET_OK;
+}
+
+extern "C" int ccnet_row_stats_bf16(const void* x, int ldx, int rows, int C, float eps, float* stats, void* stream) {
+    if (!x || !stats) return CCNET_EINVAL;
+    if (rows <= 0 || C <= 0 || (C % 8) || (ldx % 8)) return CCNET_EINVAL;
+    if (C > LN_MAXCH * 64 * 8) return CCNET_EUNSUP;
+    const int nch = (C / 8 + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* xp = (const __bf16*)x;
+    if (nch == 1) launch_row_stats<1, 4>(xp, ldx, rows, C, eps, stats, st);
+    else if (nch == 2) launch_row_stats<2, 4>(xp, ldx, rows, C, eps, stats, st);
+    else if (nch == 3) launch_row_stats<3, 2>(xp, ldx, rows, C, eps, stats, st);
+    else launch_row_stats<4, 2>(xp, ldx, rows, C, eps, stats, st);
     CCNET_LAUNCH_CHECK();
     return CCNET_OK;
 }

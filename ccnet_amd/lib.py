@@ -22,6 +22,7 @@ EXPORTS = [
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
     "ccnet_set_option", "ccnet_prof_shapes", "ccnet_conv_workspace_bytes", "ccnet_transpose_pad_bf16",
     "ccnet_attention_d64_causal_bf16", "ccnet_embed_tokens_bf16", "ccnet_gelu_bf16", "ccnet_conv_gemm_bf16_noalloc",
+    "ccnet_row_stats_bf16",
 ]
 
 
@@ -41,7 +42,7 @@ class ConvParams(C.Structure):
         ("ldres1", C.c_int32), ("ldres2", C.c_int32), ("ld_rowvec", C.c_int32),
         ("act", C.c_int32), ("scale", C.c_float), ("batch", C.c_int32),
         ("sx1", C.c_int64), ("sw", C.c_int64), ("so", C.c_int64), ("workspace", C.c_void_p),
-        ("workspace_bytes", C.c_int64),
+        ("workspace_bytes", C.c_int64), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
     ]
 
 
@@ -72,6 +73,7 @@ def load() -> C.CDLL:
     lib.ccnet_groupnorm_workspace_bytes.argtypes = [i, i, i, i]
     lib.ccnet_groupnorm_bf16.argtypes = [vp, i, i, vp, i, i, i, i, i, f, vp, vp, i, vp, i, vp, sz, vp]
     lib.ccnet_layernorm_bf16.argtypes = [vp, i, i, i, f, vp, vp, vp, i, vp]
+    lib.ccnet_row_stats_bf16.argtypes = [vp, i, i, i, f, vp, vp]
     lib.ccnet_geglu_bf16.argtypes = [vp, i, i, i, vp, i, vp]
     lib.ccnet_attention_d64_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, vp]
     lib.ccnet_attention_d64_causal_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, f, vp]

@@ -20,6 +20,7 @@ statistics stay in fp32.  There is no CPU or eager fallback: without the HIP lib
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -30,6 +31,12 @@ from .lib import CcnetError
 from .ops import Act
 
 BF16 = torch.bfloat16
+# CCNET_LN_FOLD=1: the transformer blocks' LayerNorms are folded into the GEMMs that consume them (ops.fold_layernorm +
+# ops.row_stats: the normalised rows never reach HBM, three launches per block become statistics-only passes).  Measured on
+# the whole pipeline (tools/ab_lnfold.sh, same box, batch 16): 2227 / 2231 ms per batch with the fold against 2220 / 2221
+# without -- the write it saves is served from the Infinity Cache anyway and the GEMM's accumulator start gets heavier -- so
+# the separate LayerNorm kernel stays the default and the fold is an option (parity-tested either way).
+LN_FOLD = os.environ.get("CCNET_LN_FOLD", "0") == "1"
 
 
 def _tuple(v, n):
@@ -246,7 +253,18 @@ class _Trunk(nn.Module):
         def pattn(a: _Holder):
             b = a.transformer_blocks[0]
             inner = a.heads * a.head_ch
+            # LayerNorm folded into the linear layer that consumes it (ops.fold_layernorm; the GEMM kernel applies the row
+            # statistics): norm1 -> to_q|to_k|to_v, norm2 -> attn2.to_q, norm3 -> ff.linear1 (then the GEGLU interleave)
+            f_qkv = f_q2 = f_ff1 = None
+            if LN_FOLD:
+                dv = lambda t: tuple(x.to(dev) for x in t)
+                qkv_w = torch.cat([b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight], 0)
+                f_qkv = dv(ops.fold_layernorm(qkv_w, None, b.norm1.weight, b.norm1.bias))
+                f_q2 = dv(ops.fold_layernorm(b.attn2.to_q.weight, None, b.norm2.weight, b.norm2.bias))
+                w1, b1, c1 = ops.fold_layernorm(b.ff.linear1.weight, b.ff.linear1.bias, b.norm3.weight, b.norm3.bias)
+                f_ff1 = dv((ops.geglu_interleave(w1), ops.geglu_interleave(b1), ops.geglu_interleave(c1)))
             return {
+                "qkv1f": f_qkv, "q2f": f_q2, "ff1f": f_ff1,
                 "norm": (f32(a.norm.weight), f32(a.norm.bias)), "pin": pconv(a.proj_in.conv),
                 "pout": pconv(a.proj_out.conv), "heads": a.heads, "head_ch": a.head_ch, "inner": inner,
                 "ln1": (f32(b.norm1.weight), f32(b.norm1.bias)), "ln2": (f32(b.norm2.weight), f32(b.norm2.bias)),
@@ -409,16 +427,26 @@ class _Trunk(nn.Module):
             return ops.attention_generic(q, k, v, B, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
         h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.transformer_norm_eps, False)
         t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
-        n1 = ops.layernorm(t, inner, *p["ln1"])
-        qkv = ops.linear(n1, p["qkv1"], None, 3 * inner, inner)
+        if LN_FOLD:
+            # the three LayerNorms never materialise: a statistics pass (8 B per row out) + the consuming GEMM on the raw rows
+            w, b, cs = p["qkv1f"]
+            qkv = ops.linear(t, w, b, 3 * inner, inner, rowstat=ops.row_stats(t, inner), colsum=cs)
+        else:
+            qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1"], None, 3 * inner, inner)
         o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
         t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
-        n2 = ops.layernorm(t, inner, *p["ln2"])
-        q = ops.linear(n2, p["q2"], None, inner, inner)
+        if LN_FOLD:
+            w, b, cs = p["q2f"]
+            q = ops.linear(t, w, b, inner, inner, rowstat=ops.row_stats(t, inner), colsum=cs)
+        else:
+            q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2"], None, inner, inner)
         o = attend(q, kv[:, :inner], kv[:, inner:], S)
         t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
-        n3 = ops.layernorm(t, inner, *p["ln3"])
-        gl = ops.linear(n3, p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)  # linear1 + GEGLU in one kernel
+        if LN_FOLD:  # norm3 + linear1 + GEGLU in one kernel
+            w, b, cs = p["ff1f"]
+            gl = ops.linear(t, w, b, 8 * inner, inner, act=2, rowstat=ops.row_stats(t, inner), colsum=cs)
+        else:
+            gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)
         t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
         ta = Act(t, x.N, x.H, x.W, inner)
         return ops.conv(ta, p["pout"][0], p["pout"][1], C_, R=1, pad=0, res1=x, res2=res2)

@@ -55,8 +55,11 @@ def new_act(N, H, W, Cch, device) -> Act:
 def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: int = 3, stride: int = 1,
          pad: Optional[int] = None, ups: int = 1, x2: Optional[Act] = None, rowvec: Optional[torch.Tensor] = None,
          res1: Optional[Act] = None, scale: float = 1.0, act: int = 0, res2: Optional[Act] = None,
-         out_hw: Optional[Tuple[int, int]] = None, out: Optional[Act] = None):
-    """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given."""
+         out_hw: Optional[Tuple[int, int]] = None, out: Optional[Act] = None,
+         rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None):
+    """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given.
+    rowstat / colsum: LayerNorm folded into the layer (include/ccnet_hip.h: x holds the un-normalised rows, w and bias the
+    folded parameters of `fold_layernorm`, rowstat = row_stats(x))."""
     lib = _l.load()
     _need_cuda(x.t, w)
     if pad is None:
@@ -86,6 +89,13 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
     p.ldres2 = res2.ld if res2 is not None else 0
     p.ld_rowvec = rowvec.stride(0) if rowvec is not None else 0
     p.act = act; p.scale = scale; p.batch = 1
+    if (rowstat is None) != (colsum is None):
+        raise _l.CcnetError("rowstat and colsum come together")
+    if rowstat is not None:
+        if rowstat.dtype != torch.float32 or rowstat.numel() != 2 * out.rows or colsum.dtype != torch.float32 \
+                or colsum.numel() < Cout or not rowstat.is_contiguous():
+            raise _l.CcnetError("rowstat must be fp32 [rows, 2] and colsum fp32 [>= Cout]")
+        p.rowstat = rowstat.data_ptr(); p.colsum = colsum.data_ptr()
     if w.shape[1] != R * R * (p.C1 + p.C2):
         raise _l.CcnetError(f"weight K {w.shape[1]} != R*R*(C1+C2) = {R * R * (p.C1 + p.C2)}")
     if res1 is not None and res1.rows != out.rows:
@@ -122,12 +132,36 @@ def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, Cin: int,
-           res1: Optional[torch.Tensor] = None, scale: float = 1.0, act: int = 0) -> torch.Tensor:
+           res1: Optional[torch.Tensor] = None, scale: float = 1.0, act: int = 0,
+           rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row-matrix convenience over conv(): x2d [rows, >=Cin] bf16 -> [rows, Cout] (Cout/2 with act=2, GEGLU)."""
     rows = x2d.shape[0]
     xa = Act(x2d, 1, rows, 1, Cin)
     ra = Act(res1, 1, rows, 1, Cout) if res1 is not None else None
-    return conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale, act=act).t
+    return conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale, act=act, rowstat=rowstat, colsum=colsum).t
+
+
+def row_stats(x2d: torch.Tensor, Cc: int, eps: float = 1e-5) -> torch.Tensor:
+    """fp32 [rows, 2] = (mean, 1 / sqrt(var + eps)) over the first Cc columns of every row: the statistics of the LayerNorm
+    that `linear(..., rowstat=, colsum=)` applies inside the GEMM."""
+    lib = _l.load()
+    _need_cuda(x2d)
+    out = torch.empty((x2d.shape[0], 2), dtype=torch.float32, device=x2d.device)
+    _l.check(lib.ccnet_row_stats_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], Cc, eps, out.data_ptr(), _stream()),
+             "row_stats")
+    return out
+
+
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """Parameters of `Linear(LayerNorm(x))` as one GEMM on the un-normalised x: (w_folded bf16 [N, K] = gamma o W, bias_folded
+    fp32 [N] = bias + W beta, colsum fp32 [N] = row sums of the ROUNDED folded weights -- what the kernel subtracts mean
+    times).  w fp32 / bf16 [N, K] (nn.Linear layout); gamma, beta [K]."""
+    w32 = w.detach().float()
+    wf = (w32 * gamma.detach().float()[None, :]).to(BF16).contiguous()
+    bf = w32 @ beta.detach().float()
+    if bias is not None:
+        bf = bf + bias.detach().float()
+    return wf, bf.contiguous(), wf.float().sum(dim=1).contiguous()
 
 
 def geglu_interleave(w: torch.Tensor) -> torch.Tensor:

@@ -76,6 +76,14 @@ typedef struct ccnet_conv_params {
     int64_t sx1, sw, so;  /* element strides between batch problems for x1, w, out              */
     void* workspace;      /* fp32 scratch for split-K partial sums, ccnet_conv_workspace_bytes(p) bytes (may be 0) */
     int64_t workspace_bytes;
+    /* LayerNorm folded into a linear layer (BasicTransformerBlock.norm1/2/3 -> to_q/k/v, ff.linear1): x1 holds the
+     * UN-normalised rows, w = gamma o W (rounded to bf16), bias = bias + W beta, colsum[n] = sum_k w[n][k] (of the rounded
+     * weights), rowstat[m] = {mean, rstd} of row m (ccnet_row_stats_bf16).  Then
+     *   out[m][n] = act( rstd[m] * (sum_k x1[m][k] w[n][k] - mean[m] * colsum[n]) + bias[n] ) ...
+     * = act(LayerNorm(x1)[m] . W[n] + bias[n]) without the normalised tensor ever existing in HBM.  Both NULL: plain GEMM.
+     * Needs R = 1, one source, no rowvec, batch 1; never runs split along K. */
+    const float* rowstat; /* fp32 [M][2] or NULL */
+    const float* colsum;  /* fp32 [Cout] or NULL */
 } ccnet_conv_params;
 
 int ccnet_conv_gemm_bf16(const ccnet_conv_params* p /*host*/, void* stream);
@@ -123,6 +131,10 @@ int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void* x2, int l
 /* K6: nn.LayerNorm(C, eps) over rows of a [rows][ldx] bf16 matrix (BasicTransformerBlock.norm1/2/3). */
 int ccnet_layernorm_bf16(const void* x, int ldx, int rows, int C, float eps, const float* gamma,
                          const float* beta, void* out, int ldo, void* stream);
+
+/* Row statistics for the folded LayerNorm of ccnet_conv_gemm_bf16: stats[r] = {mean, 1 / sqrt(var + eps)} over the first C
+ * columns of row r (biased variance, two-pass over registers, fp32), one read of the matrix and 8 bytes written per row. */
+int ccnet_row_stats_bf16(const void* x, int ldx, int rows, int C, float eps, float* stats /*[rows][2]*/, void* stream);
 
 /* K7: GEGLU, out[r][c] = a[r][c] * gelu_erf(g[r][c]) with a = x[:, :C], g = x[:, C:2C] (MLPBlock act="GEGLU"). */
 int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo, void* stream);

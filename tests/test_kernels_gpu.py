@@ -226,6 +226,39 @@ def test_layernorm(cuda, rows, C):
     _close(out.float(), ref, atol=1e-2, what="layernorm")
 
 
+@pytest.mark.parametrize("rows,C,N,geglu", [(300, 320, 960, False), (4096, 640, 640, False), (1000, 1280, 2560, True),
+                                            (8192, 320, 2560, True), (77, 64, 192, False), (70000, 320, 320, False)])
+def test_layernorm_folded_into_linear(cuda, rows, C, N, geglu):
+    """Linear(LayerNorm(x)) as ONE GEMM on the un-normalised rows (ccnet_row_stats_bf16 + the rowstat / colsum operands of
+    ccnet_conv_gemm_bf16) against fp32 F.layer_norm -> F.linear (-> a * gelu(gate)); rows with large means and very
+    different scales, non-trivial gamma / beta, with and without a bias, every tile configuration the dispatch picks."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(33 + rows)
+    x = torch.randn(rows, C, generator=g) * (0.2 + 4.0 * torch.rand(rows, 1, generator=g)) + 3.0 * torch.randn(rows, 1, generator=g)
+    xb = x.to(torch.bfloat16).to(cuda)
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    b = 0.3 * torch.randn(N, generator=g) if geglu else None
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    st = ops.row_stats(xb, C, 1e-5)
+    xf = xb.float()
+    assert (st[:, 0] - xf.mean(1)).abs().max().item() < 1e-4
+    assert ((st[:, 1] - (xf.var(1, unbiased=False) + 1e-5).rsqrt()).abs() * xf.std(1)).max().item() < 1e-3
+    wf, bf, cs = ops.fold_layernorm(w, b, gamma, beta)
+    ref = F.linear(F.layer_norm(xf, (C,), gamma.to(cuda), beta.to(cuda), 1e-5), w.to(cuda), None if b is None else b.to(cuda))
+    if geglu:
+        wf, bf, cs = ops.geglu_interleave(wf), ops.geglu_interleave(bf), ops.geglu_interleave(cs)
+        a, gate = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(gate)
+    out = ops.linear(xb, wf.to(cuda), bf.to(cuda), N, C, act=2 if geglu else 0, rowstat=st, colsum=cs.to(cuda))
+    assert tuple(out.shape) == tuple(ref.shape)
+    _close(out.float(), ref, atol=3e-2, what=f"LayerNorm folded into linear {rows}x{C}->{N}")
+    # and against the unfused pair of kernels (same bf16 inputs, one rounding fewer on the folded side)
+    two = ops.linear(ops.layernorm(xb, C, gamma.to(cuda), beta.to(cuda)),
+                     (ops.geglu_interleave(w) if geglu else w).to(torch.bfloat16).to(cuda),
+                     None if b is None else ops.geglu_interleave(b).to(cuda), N, C, act=2 if geglu else 0)
+    _close(out.float(), two.float(), atol=5e-2, what="folded vs LayerNorm kernel + linear")
+
+
 def test_geglu(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(41)
@@ -581,7 +614,11 @@ def test_conv_dispatch_sweep(cuda):
         mode = rnd.choice(["plain", "plain", "res", "rowvec", "scale", "geglu"])
         shapes.append((N, H, C1, C2, Cout, R, mode))
     shapes += [(32, 8, 1280, 0, 1280, 3, "res"), (32, 8, 2560, 0, 1280, 1, "plain"), (8, 32, 640, 0, 1280, 1, "res"),
-               (2, 64, 320, 0, 2560, 1, "geglu"), (32, 16, 1280, 0, 1280, 1, "res"), (32, 16, 1280, 0, 3840, 1, "plain")]
+               (2, 64, 320, 0, 2560, 1, "geglu"), (32, 16, 1280, 0, 1280, 1, "res"), (32, 16, 1280, 0, 3840, 1, "plain"),
+               # 128x320 tiles: residual-prefetch persistent instance (K = 320 with a residual, full and ragged M, two column
+               # tiles) and the one-round instance at M = 8192 without a residual
+               (32, 64, 320, 0, 320, 1, "res"), (5, 115, 320, 0, 320, 1, "res"), (16, 64, 320, 0, 640, 1, "res"),
+               (32, 16, 1280, 0, 1280, 1, "plain"), (32, 16, 640, 0, 1280, 1, "scale")]
     for (N, H, C1, C2, Cout, R, mode) in shapes:
         x1 = _rand_act(N, H, H, C1, cuda, 11)
         x2 = _rand_act(N, H, H, C2, cuda, 12) if C2 else None

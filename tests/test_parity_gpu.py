@@ -513,6 +513,25 @@ def test_overlapped_step_matches_sequential_step(cuda):
     assert psnr(res["ov_graph"]["image"], res["seq"]["image"].cpu()) >= 40.0
 
 
+def test_layernorm_fold_option_matches_default_lowering(cuda, monkeypatch):
+    """CCNET_LN_FOLD=1 (LayerNorm folded into the consuming GEMMs) against the default lowering on one UNet forward: the same
+    function of the same weights, one bf16 rounding fewer per LayerNorm."""
+    import ccnet_amd.nets as pn
+    from ccnet_amd.synthetic import init_weights
+    x, ctx, _ = _inputs(2, cuda, seed=71)
+    t = torch.tensor([400]).to(cuda)
+    outs = []
+    for fold in (False, True):
+        monkeypatch.setattr(pn, "LN_FOLD", fold)
+        u = pn.DiffusionModelUNet(out_channels=4, **TINY)
+        init_weights(u, 72)
+        outs.append(u.to(cuda).eval()(x.to(cuda), t, ctx.to(cuda)))
+    _check(outs[1], outs[0].cpu(), "LayerNorm-folded UNet vs default lowering")
+    _, o = build_pair("unet", TINY, 72, cuda)
+    with torch.no_grad():
+        _check(outs[1], o(x, torch.tensor([400]), ctx), "LayerNorm-folded UNet vs oracle")
+
+
 def test_two_phase_unet_and_embedding_table(cuda):
     """encode_phase + decode_phase is forward() cut in two (bit-identical without residuals), and a row of
     embedding_table() is what the per-step embedding MLPs produce for that timestep (fp32 summation order aside)."""

@@ -29,9 +29,14 @@ l = lib.load()
 l.ccnet_set_option(0, cfg)
 dbg = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 l.ccnet_debug_stamp_buffer.argtypes = [C.c_void_p]
-for it in range(4):
-    ops.conv(x, ws[it % 8], b, Cout, R=R, res1=res, act=act)
-torch.cuda.synchronize()
+import time
+t_end = time.perf_counter() + float(os.environ.get("STAMP_WARM_S", "2.0"))  # let the clocks settle under this load
+it = 0
+while time.perf_counter() < t_end:
+    for _ in range(16):
+        ops.conv(x, ws[it % 8], b, Cout, R=R, res1=res, act=act)
+        it += 1
+    torch.cuda.synchronize()
 l.ccnet_debug_stamp_buffer(dbg.data_ptr())
 dbg.zero_()
 ops.conv(x, ws[5], b, Cout, R=R, res1=res, act=act)
@@ -46,6 +51,12 @@ print(f"blocks {len(d)}  kernel span {(t[:, 4].max() - t[:, 0].min()):.0f} ticks
 for i, nm in enumerate(names):
     print(f"  {nm:16s} mean {ph[:, i].mean():9.0f}  p10 {np.percentile(ph[:, i], 10):9.0f}  p90 {np.percentile(ph[:, i], 90):9.0f}")
 print(f"  per-block total  mean {(t[:, 4] - t[:, 0]).mean():9.0f}")
+# in-kernel clock over the main loop: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime), slots 5 / 6
+rt = (d[:, 6] - d[:, 5]).astype(np.float64)
+ok = rt > 0
+if ok.any():
+    clk = (t[ok, 3] - t[ok, 2]) / rt[ok] * 0.1
+    print(f"  main-loop clock  median {np.median(clk):.3f} GHz  p10 {np.percentile(clk, 10):.3f}  p90 {np.percentile(clk, 90):.3f}")
 
 # persistent launches: stamps 2..4 exist per tile (slot = virtual block); look at lockstep between the CUs
 full = dbg.cpu().numpy().reshape(-1, 8)
