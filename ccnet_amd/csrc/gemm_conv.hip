@@ -68,9 +68,10 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wa
                                              0, 0);
 }
 
-// GEGLU = true: the packed weight rows interleave 32-row blocks of the "a" half and the "gate" half of an
-// MLPBlock(act="GEGLU").linear1, so accumulators (2p, j) and (2p+1, j) of a wave hold a and gate of the same
-// outputs in the same lane/register; the epilogue writes a * gelu_erf(gate) (Cout/2 columns).
+// GEGLU = true: the packed weight rows interleave 8-row blocks of the "a" half and the "gate" half of an
+// MLPBlock(act="GEGLU").linear1, so register quads (2h, 2h+1) of every accumulator hold a and gate of the same 4
+// outputs in the same lane; the epilogue writes a * gelu_erf(gate) (Cout/2 columns, 16 per accumulator block).
+// Any TI works (the 256x320 tile included); the interleave unit is the 8 couts a lane pair (hh = 0, 1) owns per quad.
 // PERSIST = true: the grid is at most one block per CU slot and each block walks tiles b, b + grid, b + 2 grid, ...;
 // the next tile's first NS-1 stages are issued BEFORE the current tile's epilogue, so a short-K layer's tile start-up
 // (address set-up, HBM/L2 latency of the first stages) hides under the previous tile's stores.
@@ -353,8 +354,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     // ---------------------------------------------------------------- epilogue
     // Straight from the accumulators, no LDS: after v_permlane32_swap of the (q even, q odd) register pairs a lane
     // holds 8 consecutive couts of its pixel, i.e. one 16-B store (and one 16-B residual load) per 16 columns.
-    static_assert(!GEGLU || (TI % 2) == 0, "GEGLU pairs accumulator blocks");
-    constexpr int TIO = GEGLU ? TI / 2 : TI;  // 32-column output blocks per wave
+    constexpr int TIO = TI;                // output blocks per wave: one per accumulator block,
+    constexpr int OBW = GEGLU ? 16 : 32;   // 16 columns wide under GEGLU (a and gate share the block), else 32
+    constexpr int NP = GEGLU ? 1 : 2;      // 16-column store groups per output block
     __bf16* outp = a.out + (long long)z * a.so;
     const int cout_out = GEGLU ? a.Cout / 2 : a.Cout;
     const int ncol0 = (GEGLU ? cn0 / 2 + wn * 16 * TI : cn0 + wn * 32 * TI) + 8 * hh;
@@ -420,18 +422,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                 for (int k = 0; k < 16; ++k) acc[i][j][k] *= ln_rstd[j];
     }
     if constexpr (GEGLU) {
+        // quads (0, 1) -> outputs 4 hh + e, quads (2, 3) -> outputs 8 + 4 hh + e of the block's 16; the results land in
+        // registers 0..7, i.e. in the layout the first 16-column store group of a plain block has
 #pragma unroll
-        for (int ob = 0; ob < TIO; ++ob)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const f32x16 &va = acc[2 * ob][j], &vg = acc[2 * ob + 1][j];
-                        const f32x2 r = geglu_pk(f32x2{va[4 * q + e], va[4 * q + e + 1]}, f32x2{vg[4 * q + e], vg[4 * q + e + 1]});
-                        acc[2 * ob][j][4 * q + e] = r[0];
-                        acc[2 * ob][j][4 * q + e + 1] = r[1];
+                        const f32x16& v = acc[i][j];
+                        const f32x2 r = geglu_pk(f32x2{v[8 * h2 + e], v[8 * h2 + e + 1]}, f32x2{v[8 * h2 + 4 + e], v[8 * h2 + 5 + e]});
+                        acc[i][j][4 * h2 + e] = r[0];
+                        acc[i][j][4 * h2 + e + 1] = r[1];
                     }
                     __builtin_amdgcn_sched_barrier(0);  // four GELU chains in flight at a time (register budget)
                 }
@@ -453,7 +457,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[i][j][k] *= a.scale;
     }
-    constexpr int AS = GEGLU ? 2 : 1;  // accumulator block of output block ob
     if (a.res1 == nullptr && a.out2 == nullptr) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -463,13 +466,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 #pragma unroll
             for (int ob = 0; ob < TIO; ++ob)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const f32x16& v = acc[AS * ob][j];
+                for (int p = 0; p < NP; ++p) {
+                    const f32x16& v = acc[ob][j];
                     unsigned d0 = pack_bf16x2(v[8 * p], v[8 * p + 1]), d1 = pack_bf16x2(v[8 * p + 2], v[8 * p + 3]);
                     unsigned d2 = pack_bf16x2(v[8 * p + 4], v[8 * p + 5]), d3 = pack_bf16x2(v[8 * p + 6], v[8 * p + 7]);
                     swap32(d0, d2);
                     swap32(d1, d3);
-                    const int ncol = ncol0 + ob * 32 + 16 * p;
+                    const int ncol = ncol0 + ob * OBW + 16 * p;
                     if (mok && ncol < cout_out) *(u32x4*)(orow + ncol) = u32x4{d0, d1, d2, d3};
                 }
         }
@@ -489,12 +492,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
             for (int ob0 = 0; ob0 < TIO; ob0 += OBG) {
                 // residual loads of up to OBG output blocks are issued together, ahead of the arithmetic; a missing
                 // residual is predicated off per lane (no branch), its registers then hold zeros
-                u32x4 rr1[OBG][2], rr2[OBG][2];
+                u32x4 rr1[OBG][NP], rr2[OBG][NP];
 #pragma unroll
                 for (int oo = 0; oo < OBG; ++oo)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int ncol = ncol0 + (ob0 + oo) * 32 + 16 * p;
+                    for (int p = 0; p < NP; ++p) {
+                        const int ncol = ncol0 + (ob0 + oo) * OBW + 16 * p;
                         const bool ok = ob0 + oo < TIO && mok && ncol < cout_out;
                         if constexpr (RESPRE) rr1[oo][p] = rpre[j][ob0 + oo < TIO ? ob0 + oo : 0][p];
                         else rr1[oo][p] = (ok && has1) ? *(const u32x4*)(r1row + ncol) : u32x4{0u, 0u, 0u, 0u};
@@ -505,8 +508,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                     const int ob = ob0 + oo;
                     if (ob >= TIO) continue;
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const f32x16& v = acc[AS * ob][j];
+                    for (int p = 0; p < NP; ++p) {
+                        const f32x16& v = acc[ob][j];
                         float w[8], r[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
                         unpack8(rr1[oo][p], r);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) w[e] += r[e];
-                        const int ncol = ncol0 + ob * 32 + 16 * p;
+                        const int ncol = ncol0 + ob * OBW + 16 * p;
                         const bool ok = mok && ncol < cout_out;
                         if (ok) *(u32x4*)(orow + ncol) = pack8(w);
                         unpack8(rr2[oo][p], r);
@@ -658,7 +661,8 @@ const TileCfg kCfgs[] = {
     {128, 128, launch<4, 2, 1, 2, false, 3>, nullptr, launch<4, 2, 1, 2, false, 3, 64, true>},  // 19: 8 waves, 3 stages
     {256, 256, launch<4, 2, 2, 4, false, 4, 32, false, true>, launch<4, 2, 2, 4, true, 4, 32, false, true>, nullptr},    // 20: 8 waves, 4 x 32-deep
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 21-22
-    {256, 320, launch<4, 2, 2, 5, false, 2, 64, false, true>, nullptr, launch<4, 2, 2, 5, false, 2, 64, true>},  // 23: 8 waves
+    {256, 320, launch<4, 2, 2, 5, false, 2, 64, false, true>, launch<4, 2, 2, 5, true, 2, 64, false, true>,
+     launch<4, 2, 2, 5, false, 2, 64, true>},                                    // 23: 8 waves
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 24-25
     {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>, nullptr},    // 26: 4 waves, 72 KB
     {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr, launch<2, 2, 2, 5, false, 2, 32, true>},  // 27: 4 waves, 57 KB
@@ -691,6 +695,8 @@ int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, in
     auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * batch; };
     if (geglu) {
         if (forced) return g_force_cfg;
+        // 256x320 (2 x 64-deep stages) where it fills whole rounds: ff.linear1 of every G1 level (2560 / 5120 / 10240 couts)
+        if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
         // 256x256 where it fills whole rounds or most of one; between them (257..399 tiles) the second round runs half empty
         const long long t = (Cout % 256) == 0 ? tiles(256, 256) : 0;
         if (t >= 400 || (t >= 128 && t <= 256)) return 20;

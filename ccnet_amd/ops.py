@@ -166,10 +166,11 @@ def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.T
 
 def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     """Reorder the rows of MLPBlock.linear1 (weight [2H, C] or bias [2H]; value half first, gate half second) into
-    alternating 32-row blocks [a0..31, g0..31, a32..63, g32..63, ...] as the act=2 epilogue expects."""
+    alternating 8-row blocks [a0..7, g0..7, a8..15, g8..15, ...] as the act=2 epilogue expects (the 8 couts that a lane pair
+    of the MFMA accumulator layout owns per register quad: value and gate of an output meet in one lane)."""
     H = w.shape[0] // 2
     a, g = w[:H], w[H:]
-    sh = (H // 32, 32) + tuple(w.shape[1:])
+    sh = (H // 8, 8) + tuple(w.shape[1:])
     return torch.stack([a.reshape(sh), g.reshape(sh)], dim=1).reshape(w.shape).contiguous()
 
 

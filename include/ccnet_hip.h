@@ -69,7 +69,7 @@ typedef struct ccnet_conv_params {
     int32_t stride, pad;  /* pad_lo; the high side is implied by Hout/Wout                      */
     int32_t ups;          /* 1, or 2 = nearest-neighbour x2 upsample folded into the gather     */
     int32_t ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec;  /* row strides in elements  */
-    int32_t act;          /* 0 none, 1 SiLU, 2 GEGLU: w/bias rows interleave 32-row blocks of the value and
+    int32_t act;          /* 0 none, 1 SiLU, 2 GEGLU: w/bias rows interleave 8-row blocks of the value and
                              gate halves of MLPBlock.linear1; out has Cout/2 columns = a * gelu_erf(gate)      */
     float scale;
     int32_t batch;        /* >1: batched plain GEMM (R==1); z-th problem uses the strides below */
