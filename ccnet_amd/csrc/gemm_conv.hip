@@ -20,6 +20,7 @@
 // give each lane 8 consecutive couts of its pixel, i.e. one 16-B store / residual load per 16 columns.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -51,6 +52,8 @@ struct ConvArgs {
     int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
     long long sx1, sw, so;
     const float* rowstat; const float* colsum;  // LayerNorm folded into the GEMM (see the accumulator start)
+    int rowstat_parts; float ln_eps;            // > 0: rowstat holds that many (mean, M2) partials per row (a producer's stat_out)
+    float* stat_out; int stat_parts;            // STAT instances: per-row (mean, M2) of every 32*TI-column span of the output
     float* out32; int cout_real;  // SPLIT instances only: != nullptr -> final fp32 NCHW output (+ bias), Cout <= 8 edge convs
     int splitk;   // > 1: blockIdx.y selects a K slice, raw fp32 partial sums go to ws[slice][M][Cout]
     float* ws;
@@ -81,10 +84,16 @@ __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wa
 // 26k of the 35k epilogue cycles of a 256x320 tile, stamps in profiles/r02_stamp_clock.txt) -- so the memory time adds to the
 // MFMA time.  Prefetching spreads the residual read over the K loop; the prefetched tile does not fit L2 (164 KB per CU x
 // 32 CUs per XCD > 4 MB), so registers are the only place, and only the 80-accumulator 128x320 tile has 40 to spare.
-template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK, bool SPLIT, bool PERSIST, bool RESPRE = false>
+// STAT = true: the epilogue also writes, for every output row and every span of 32*TI columns (a wave's share of the row),
+// the span's (mean, M2) in fp32 to stat_out[row][span][2] -- the statistics of the LayerNorm that follows the layer, taken
+// from the fp32 values on their way out (shifted sums around the lane's first value, Chan merge of the two lane halves), so
+// the consumer (rowstat / rowstat_parts of the next GEMM) needs no pass over the tensor.
+template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS, int BK, bool SPLIT, bool PERSIST, bool RESPRE = false,
+          bool STAT = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs a) {
     static_assert(!(SPLIT && PERSIST), "split-K launches are never persistent");
     static_assert(!RESPRE || (!SPLIT && !GEGLU), "residual prefetch: plain epilogue only");
+    static_assert(!STAT || (!SPLIT && !GEGLU), "row statistics: plain epilogue only");
     constexpr int NT = 64 * WM * WN, BM = 32 * TJ * WM, BN = 32 * TI * WN;
     static_assert(BK == 64 || BK == 32, "K-step of 64 or 32 channels");
     constexpr int CPW = BK / 8;            // 16-B chunks per tile row
@@ -244,7 +253,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     for (int j = 0; j < TJ; ++j) {
         const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
         f32x2 st = {0.f, 1.f};
-        if (ln) st = *(const f32x2*)(a.rowstat + 2ll * (m < a.M ? m : a.M - 1));
+        if (ln) {
+            const long long mm = m < a.M ? m : a.M - 1;
+            if (a.rowstat_parts == 0) {
+                st = *(const f32x2*)(a.rowstat + 2ll * mm);
+            } else {
+                // (mean, M2) of P equal column spans of the row, written by the producing layer's epilogue: Chan merge.
+                // (Two dependent rounds of loads at the head of every tile: measured +18 % on the GEGLU layer.  A single
+                // round of 16-byte loads needs registers the 160-accumulator instance does not have: it spilled.)
+                const int P = a.rowstat_parts;
+                const float* rp = a.rowstat + 2ll * mm * P;
+                const float span = (float)(a.C1 / P);
+                float ms = 0.f;
+                for (int q = 0; q < P; ++q) ms += rp[2 * q];
+                const float mean = ms / (float)P;
+                float m2 = 0.f;
+                for (int q = 0; q < P; ++q) { const float d = rp[2 * q] - mean; m2 += rp[2 * q + 1] + d * d * span; }
+                st = f32x2{mean, rsqrtf(m2 / (float)a.C1 + a.ln_eps)};
+            }
+        }
         ln_mean[j] = st[0];
         ln_rstd[j] = st[1];
         ln_sigma[j] = ln ? 1.0f / st[1] : 1.0f;
@@ -283,8 +310,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         }
     }
 
-    // residual prefetch: the epilogue's layout (after the permlane32 swap a lane owns 8 consecutive couts of its pixel)
-    u32x4 rpre[RESPRE ? TJ : 1][RESPRE ? TI : 1][2];
+    // residual prefetch: the epilogue's layout (after the permlane32 swap a lane owns 8 consecutive couts of its pixel);
+    // STAT instances add the residual before the swap, so they prefetch in the accumulator layout (quads of 4 couts)
+    u32x4 rpre[(RESPRE && !STAT) ? TJ : 1][(RESPRE && !STAT) ? TI : 1][2];
+    u32x2 rpre4[(RESPRE && STAT) ? TJ : 1][(RESPRE && STAT) ? TI : 1][4];
     if constexpr (RESPRE) {
         const bool has1 = a.res1 != nullptr;
 #pragma unroll
@@ -292,12 +321,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
             const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
             const __bf16* r1row = a.res1 + (long long)m * a.ldres1;
 #pragma unroll
-            for (int ob = 0; ob < TI; ++ob)
+            for (int ob = 0; ob < TI; ++ob) {
+                if constexpr (STAT) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int ncol = cn0 + wn * 32 * TI + 8 * hh + ob * 32 + 16 * p;
-                    rpre[j][ob][p] = (has1 && m < a.M && ncol < a.Cout) ? *(const u32x4*)(r1row + ncol) : u32x4{0u, 0u, 0u, 0u};
+                    for (int q = 0; q < 4; ++q) {
+                        const int ncol = cn0 + wn * 32 * TI + ob * 32 + 8 * q + 4 * hh;
+                        rpre4[j][ob][q] = (has1 && m < a.M && ncol < a.Cout) ? *(const u32x2*)(r1row + ncol) : u32x2{0u, 0u};
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int ncol = cn0 + wn * 32 * TI + 8 * hh + ob * 32 + 16 * p;
+                        rpre[j][ob][p] = (has1 && m < a.M && ncol < a.Cout) ? *(const u32x4*)(r1row + ncol) : u32x4{0u, 0u, 0u, 0u};
+                    }
                 }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);  // issued here, before the K loop; consumed after it
     }
@@ -457,7 +495,64 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[i][j][k] *= a.scale;
     }
-    if (a.res1 == nullptr && a.out2 == nullptr) {
+    if constexpr (STAT) {
+        // Three passes over the accumulators, so that no pass carries another's state (the 160-accumulator tile has no
+        // registers to spare): (1) the residual is added in the ACCUMULATOR layout -- a lane's register quad q of block i is
+        // couts 32 i + 8 q + 4 hh .. + 3 of its pixel, an 8-byte load -- so nothing is exchanged between lanes yet; (2) the
+        // row statistics of the finished values; (3) pack, permlane32 swap and store as the plain epilogue does.
+        const bool has1 = a.res1 != nullptr;
+        if (has1) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
+                const __bf16* r1row = a.res1 + (long long)(m < a.M ? m : a.M - 1) * a.ldres1 + cn0 + wn * 32 * TI + 4 * hh;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    u32x2 rr[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (RESPRE) rr[q] = rpre4[j][i][q];
+                        else rr[q] = cn0 + wn * 32 * TI + i * 32 + 8 * q + 4 * hh < a.Cout ? *(const u32x2*)(r1row + i * 32 + 8 * q) : u32x2{0u, 0u};
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[i][j][4 * q] += __uint_as_float(rr[q][0] << 16);
+                        acc[i][j][4 * q + 1] += __uint_as_float(rr[q][0] & 0xffff0000u);
+                        acc[i][j][4 * q + 2] += __uint_as_float(rr[q][1] << 16);
+                        acc[i][j][4 * q + 3] += __uint_as_float(rr[q][1] & 0xffff0000u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one block's residual loads in flight at a time (register budget)
+                }
+            }
+        }
+        if (a.stat_out) {
+            // shifted sums around the lane's first value (robust against a large row mean), Chan merge with lane ^ 32
+            constexpr float n = 16.0f * TI;  // values per lane and row; the other half of the span sits in lane ^ 32
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const float c = acc[0][j][0];
+                float ss = 0.f, sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float d = acc[i][j][k] - c;
+                        ss += d;
+                        sq = fmaf(d, d, sq);
+                    }
+                const float mean = c + ss * (1.0f / n);
+                const float m2 = fmaxf(sq - ss * ss * (1.0f / n), 0.f);
+                const float mean_b = __shfl_xor(mean, 32), m2_b = __shfl_xor(m2, 32);
+                const float d = mean - mean_b;
+                const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
+                if (hh == 0 && m < a.M)
+                    *(f32x2*)(a.stat_out + ((long long)m * a.stat_parts + (cn0 / (32 * TI) + wn)) * 2) =
+                        f32x2{0.5f * (mean + mean_b), m2 + m2_b + d * d * (0.5f * n)};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (STAT || (a.res1 == nullptr && a.out2 == nullptr)) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
@@ -607,7 +702,7 @@ constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
 template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false, bool PERSIST = false,
-          bool RESPRE = false>
+          bool RESPRE = false, bool STAT = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
@@ -615,12 +710,13 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     // property of the function, idempotent to set; the flag is only an optimisation)
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST, RESPRE>,
+        if (hipFuncSetAttribute((const void*)conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST, RESPRE, STAT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set.store(true, std::memory_order_release);
     }
     ConvArgs b = a;
+    if (STAT) b.stat_parts = a.Cout / (32 * TI);
     b.CT1 = a.C1 / BK; b.CT = (a.C1 + a.C2) / BK; b.KT = a.R * a.R * b.CT;
     b.tilesN = (a.Cout + BN - 1) / BN;
     b.tilesM = (a.M + BM - 1) / BM;
@@ -630,7 +726,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     // start-up is a small share and the hardware's dynamic block placement balances ragged tiles better)
     const int kmax = GEGLU ? 1280 : 640;
     const int grid = PERSIST && g_persist && b.KT * BK <= (g_persist > 1 ? g_persist : kmax) && b.tiles > kNumCUs ? kNumCUs : b.tiles;
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST, RESPRE>), dim3(grid, SPLIT ? b.splitk : 1, batch),
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TJ, TI, GEGLU, NS, BK, SPLIT, PERSIST, RESPRE, STAT>), dim3(grid, SPLIT ? b.splitk : 1, batch),
                        dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
     if (SPLIT && !b.out32) {
@@ -643,7 +739,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
 }
 
 typedef int (*LaunchFn)(const ConvArgs&, int, hipStream_t);
-struct TileCfg { int bm, bn; LaunchFn fn, fn_geglu, fn_split; };
+struct TileCfg { int bm, bn; LaunchFn fn, fn_geglu, fn_split; LaunchFn fn_stat = nullptr; int stat_span = 0; };
 // Indices are stable (tools/bench_conv.py --cfgs): entries that lost every measurement were removed and stay empty.
 const TileCfg kCfgs[] = {
     {128, 128, launch<2, 2, 2, 2, false>, launch<2, 2, 2, 2, true>, nullptr},   // 0: 4 waves, two blocks per CU
@@ -662,13 +758,15 @@ const TileCfg kCfgs[] = {
     {256, 256, launch<4, 2, 2, 4, false, 4, 32, false, true>, launch<4, 2, 2, 4, true, 4, 32, false, true>, nullptr},    // 20: 8 waves, 4 x 32-deep
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 21-22
     {256, 320, launch<4, 2, 2, 5, false, 2, 64, false, true>, launch<4, 2, 2, 5, true, 2, 64, false, true>,
-     launch<4, 2, 2, 5, false, 2, 64, true>},                                    // 23: 8 waves
+     launch<4, 2, 2, 5, false, 2, 64, true>, launch<4, 2, 2, 5, false, 2, 64, false, false, false, true>, 160},  // 23: 8 waves (the statistics instance is not persistent: no registers left for the next tile's gather state)
     {0, 0, nullptr, nullptr, nullptr}, {0, 0, nullptr, nullptr, nullptr},        // 24-25
     {128, 256, launch<2, 2, 2, 4, false, 3, 32>, launch<2, 2, 2, 4, true, 3, 32>, nullptr},    // 26: 4 waves, 72 KB
     {128, 320, launch<2, 2, 2, 5, false, 2, 32>, nullptr, launch<2, 2, 2, 5, false, 2, 32, true>},  // 27: 4 waves, 57 KB
     {128, 128, launch<2, 2, 2, 2, false, 3, 32>, nullptr, nullptr},              // 28: 48 KB: three blocks per CU
-    {128, 320, launch<4, 2, 1, 5, false, 2, 64>, nullptr, nullptr},              // 29: 8 waves of 32 x 160, 114 KB
-    {128, 320, launch<4, 2, 1, 5, false, 2, 64, false, true, true>, nullptr, nullptr},  // 30: 29, persistent, residual prefetch
+    {128, 320, launch<4, 2, 1, 5, false, 2, 64>, nullptr, nullptr,
+     launch<4, 2, 1, 5, false, 2, 64, false, false, false, true>, 160},          // 29: 8 waves of 32 x 160, 114 KB
+    {128, 320, launch<4, 2, 1, 5, false, 2, 64, false, true, true>, nullptr, nullptr,
+     launch<4, 2, 1, 5, false, 2, 64, false, true, true, true>, 160},            // 30: 29, persistent, residual prefetch
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // 256 pixels x 32 couts, 4 waves, two blocks per CU: the output convolutions (Cout <= 8); raw-accumulator epilogue
@@ -843,6 +941,18 @@ extern "C" size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p) {
     return S > 1 ? (size_t)S * M * p->Cout * sizeof(float) : 0;
 }
 
+extern "C" int ccnet_conv_stat_parts(const ccnet_conv_params* p) {
+    if (!p || p->C1 <= 0 || p->Cout <= 0 || p->N <= 0 || p->act == 2 || p->batch > 1) return 0;
+    const int KT = p->R * p->R * ((p->C1 + p->C2) / 64);
+    const int M = p->N * p->Hout * p->Wout;
+    int S = 1;
+    // the same plan ccnet_conv_gemm_bf16 will make for these parameters (a workspace is assumed present, as ops.conv brings one)
+    const int cfg_i = plan_conv(M, p->Cout, KT, 1, false, !p->rowstat, &S, p->res1 && !p->out2);
+    const TileCfg& cfg = kCfgs[cfg_i];
+    if (S > 1 || !cfg.fn_stat || (p->Cout % cfg.stat_span)) return 0;
+    return p->Cout / cfg.stat_span;
+}
+
 namespace {
 // Shared body of ccnet_conv_gemm_bf16 (workspace from the caller, `ws_limit_code` = CCNET_EWS) and of
 // ccnet_conv_gemm_bf16_noalloc (workspace = the library's static device array, no profiling records: those create events).
@@ -866,6 +976,9 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     if (p->act == 2 && p->rowvec) return CCNET_EUNSUP;  // GEGLU: interleaved 32-row a / gate blocks
     if ((p->rowstat != nullptr) != (p->colsum != nullptr)) return CCNET_EINVAL;
     if (p->rowstat && (p->R != 1 || p->C2 != 0 || p->rowvec || batch > 1 || p->stride != 1 || p->ups != 1)) return CCNET_EUNSUP;
+    if (p->rowstat && p->rowstat_parts != 0 && p->rowstat_parts != 2 && p->rowstat_parts != 4 && p->rowstat_parts != 8) return CCNET_EUNSUP;
+    if (p->rowstat && p->rowstat_parts > 0 && (p->C1 % p->rowstat_parts)) return CCNET_EINVAL;
+    if (p->stat_out && (p->act == 2 || batch > 1)) return CCNET_EUNSUP;
     // every gathered tap must fall inside the (upsampled) input or be a padding tap: checked in-kernel by
     // coordinates; here make sure the implied geometry is self-consistent so no row can index past x1/x2.
     const long long Hl = (long long)p->Hin * p->ups, Wl = (long long)p->Win * p->ups;
@@ -875,7 +988,8 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     ConvArgs a{};
     a.x1 = (const __bf16*)p->x1; a.x2 = (const __bf16*)p->x2; a.w = (const __bf16*)p->w;
     a.bias = p->bias; a.rowvec = p->rowvec; a.res1 = (const __bf16*)p->res1; a.res2 = (const __bf16*)p->res2;
-    a.rowstat = p->rowstat; a.colsum = p->colsum;
+    a.rowstat = p->rowstat; a.colsum = p->colsum; a.rowstat_parts = p->rowstat_parts; a.ln_eps = p->ln_eps;
+    a.stat_out = p->stat_out;
     a.out = (__bf16*)p->out; a.out2 = (__bf16*)p->out2;
     a.N = p->N; a.Hin = p->Hin; a.Win = p->Win; a.Hout = p->Hout; a.Wout = p->Wout;
     a.C1 = p->C1; a.C2 = p->C2; a.Cout = p->Cout; a.R = p->R; a.stride = p->stride; a.pad = p->pad; a.ups = p->ups;
@@ -923,7 +1037,13 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
         a.ws = (float*)ws;
     }
     const TileCfg& cfg = kCfgs[cfg_i];
-    const int rc = a.splitk > 1 ? cfg.fn_split(a, batch, st) : geglu ? cfg.fn_geglu(a, batch, st) : cfg.fn(a, batch, st);
+    // row statistics come from the K-loop kernel's epilogue: only unsplit plans on the tiles that have the instance
+    if (p->stat_out && (a.splitk > 1 || !cfg.fn_stat || (p->Cout % cfg.stat_span))) {
+        if (rec) --g_prof_used;  // (nothing was launched: drop the half-made profiling record)
+        return CCNET_EUNSUP;
+    }
+    const int rc = a.splitk > 1 ? cfg.fn_split(a, batch, st) : geglu ? cfg.fn_geglu(a, batch, st)
+                 : p->stat_out ? cfg.fn_stat(a, batch, st) : cfg.fn(a, batch, st);
     if (rec) (void)hipEventRecord(rec->e1, st);
     return rc;
 }

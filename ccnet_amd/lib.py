@@ -22,7 +22,7 @@ EXPORTS = [
     "ccnet_to_uint8", "ccnet_prof_enable", "ccnet_prof_collect", "ccnet_pointwise_nchw_f32", "ccnet_axpy_f32",
     "ccnet_set_option", "ccnet_prof_shapes", "ccnet_conv_workspace_bytes", "ccnet_transpose_pad_bf16",
     "ccnet_attention_d64_causal_bf16", "ccnet_embed_tokens_bf16", "ccnet_gelu_bf16", "ccnet_conv_gemm_bf16_noalloc",
-    "ccnet_row_stats_bf16",
+    "ccnet_row_stats_bf16", "ccnet_conv_stat_parts",
 ]
 
 
@@ -43,6 +43,7 @@ class ConvParams(C.Structure):
         ("act", C.c_int32), ("scale", C.c_float), ("batch", C.c_int32),
         ("sx1", C.c_int64), ("sw", C.c_int64), ("so", C.c_int64), ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
+        ("rowstat_parts", C.c_int32), ("ln_eps", C.c_float), ("stat_out", C.c_void_p),
     ]
 
 
@@ -66,6 +67,8 @@ def load() -> C.CDLL:
     lib.ccnet_conv_gemm_bf16.argtypes = [C.POINTER(ConvParams), vp]
     lib.ccnet_conv_gemm_bf16_noalloc.argtypes = [C.POINTER(ConvParams), vp]
     lib.ccnet_conv_workspace_bytes.argtypes = [C.POINTER(ConvParams)]
+    lib.ccnet_conv_stat_parts.argtypes = [C.POINTER(ConvParams)]
+    lib.ccnet_conv_stat_parts.restype = C.c_int
     lib.ccnet_conv_workspace_bytes.restype = sz
     lib.ccnet_conv_in_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, i, vp, i, i, vp, i, i, i, vp]
     lib.ccnet_conv_out_small.argtypes = [vp, i, i, i, i, i, vp, vp, i, vp, vp]

@@ -426,26 +426,31 @@ class _Trunk(nn.Module):
                 return ops.attention_d64(q, k, v, B, heads, T, Skv, scale)
             return ops.attention_generic(q, k, v, B, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
         h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.transformer_norm_eps, False)
-        t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
         if LN_FOLD:
-            # the three LayerNorms never materialise: a statistics pass (8 B per row out) + the consuming GEMM on the raw rows
+            # The three LayerNorms never materialise.  Their row statistics come out of the epilogue of the layer that writes
+            # the rows (per-span partials, ops.conv(emit_stats=True); a plan that cannot emit them falls back to a statistics
+            # pass), and the consuming GEMM applies them to the raw rows (folded gamma / beta, ops.fold_layernorm).
+            stats_of = lambda tt, st: st if st is not None else ops.row_stats(tt, inner)
+            ta, st = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0, emit_stats=True)
+            t = ta.t
             w, b, cs = p["qkv1f"]
-            qkv = ops.linear(t, w, b, 3 * inner, inner, rowstat=ops.row_stats(t, inner), colsum=cs)
-        else:
-            qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1"], None, 3 * inner, inner)
-        o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
-        t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
-        if LN_FOLD:
+            qkv = ops.linear(t, w, b, 3 * inner, inner, rowstat=stats_of(t, st), colsum=cs)
+            o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
+            t, st = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t, emit_stats=True)
             w, b, cs = p["q2f"]
-            q = ops.linear(t, w, b, inner, inner, rowstat=ops.row_stats(t, inner), colsum=cs)
+            q = ops.linear(t, w, b, inner, inner, rowstat=stats_of(t, st), colsum=cs)
+            o = attend(q, kv[:, :inner], kv[:, inner:], S)
+            t, st = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t, emit_stats=True)
+            w, b, cs = p["ff1f"]  # norm3 + linear1 + GEGLU in one kernel
+            gl = ops.linear(t, w, b, 8 * inner, inner, act=2, rowstat=stats_of(t, st), colsum=cs)
         else:
+            t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
+            qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1"], None, 3 * inner, inner)
+            o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
+            t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
             q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2"], None, inner, inner)
-        o = attend(q, kv[:, :inner], kv[:, inner:], S)
-        t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
-        if LN_FOLD:  # norm3 + linear1 + GEGLU in one kernel
-            w, b, cs = p["ff1f"]
-            gl = ops.linear(t, w, b, 8 * inner, inner, act=2, rowstat=ops.row_stats(t, inner), colsum=cs)
-        else:
+            o = attend(q, kv[:, :inner], kv[:, inner:], S)
+            t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
             gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)
         t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
         ta = Act(t, x.N, x.H, x.W, inner)

@@ -56,10 +56,13 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
          pad: Optional[int] = None, ups: int = 1, x2: Optional[Act] = None, rowvec: Optional[torch.Tensor] = None,
          res1: Optional[Act] = None, scale: float = 1.0, act: int = 0, res2: Optional[Act] = None,
          out_hw: Optional[Tuple[int, int]] = None, out: Optional[Act] = None,
-         rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None):
+         rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+         emit_stats: bool = False):
     """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given.
     rowstat / colsum: LayerNorm folded into the layer (include/ccnet_hip.h: x holds the un-normalised rows, w and bias the
-    folded parameters of `fold_layernorm`, rowstat = row_stats(x))."""
+    folded parameters of `fold_layernorm`, rowstat = row_stats(x) [rows, 2], or a producer's partials [rows, P, 2]).
+    emit_stats: returns (Act, stats) with stats = the per-row (mean, M2) partials [rows, P, 2] of the output, taken in the
+    epilogue, or None when the layer's plan cannot emit them (the caller then runs row_stats on the output)."""
     lib = _l.load()
     _need_cuda(x.t, w)
     if pad is None:
@@ -92,17 +95,28 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
     if (rowstat is None) != (colsum is None):
         raise _l.CcnetError("rowstat and colsum come together")
     if rowstat is not None:
-        if rowstat.dtype != torch.float32 or rowstat.numel() != 2 * out.rows or colsum.dtype != torch.float32 \
-                or colsum.numel() < Cout or not rowstat.is_contiguous():
-            raise _l.CcnetError("rowstat must be fp32 [rows, 2] and colsum fp32 [>= Cout]")
-        p.rowstat = rowstat.data_ptr(); p.colsum = colsum.data_ptr()
+        parts = rowstat.shape[1] if rowstat.dim() == 3 else 0
+        if rowstat.dtype != torch.float32 or rowstat.numel() != 2 * out.rows * max(parts, 1) or colsum.dtype != torch.float32 \
+                or colsum.numel() < Cout or not rowstat.is_contiguous() or (parts and x.C % parts):
+            raise _l.CcnetError("rowstat must be fp32 [rows, 2] or [rows, P, 2] with P | C1, and colsum fp32 [>= Cout]")
+        p.rowstat = rowstat.data_ptr(); p.colsum = colsum.data_ptr(); p.rowstat_parts = parts; p.ln_eps = ln_eps
     if w.shape[1] != R * R * (p.C1 + p.C2):
         raise _l.CcnetError(f"weight K {w.shape[1]} != R*R*(C1+C2) = {R * R * (p.C1 + p.C2)}")
     if res1 is not None and res1.rows != out.rows:
         raise _l.CcnetError("res1 rows mismatch")
     if rowvec is not None and (rowvec.shape[0] != x.N or rowvec.shape[1] < Cout or rowvec.dtype != torch.float32):
         raise _l.CcnetError("rowvec must be fp32 [N, >=Cout]")
+    stats = None
+    if emit_stats:
+        if out2 is not None:
+            raise _l.CcnetError("emit_stats and res2 do not combine")
+        parts = lib.ccnet_conv_stat_parts(C.byref(p))
+        if parts in (2, 4, 8):  # what a consuming GEMM merges (rowstat_parts)
+            stats = torch.empty((out.rows, parts, 2), dtype=torch.float32, device=x.t.device)
+            p.stat_out = stats.data_ptr()
     _launch_conv(p, x.t.device, "conv_gemm")
+    if emit_stats:
+        return out, stats
     return (out, out2) if out2 is not None else out
 
 
@@ -133,12 +147,16 @@ def gemm_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, Nn
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, Cin: int,
            res1: Optional[torch.Tensor] = None, scale: float = 1.0, act: int = 0,
-           rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Row-matrix convenience over conv(): x2d [rows, >=Cin] bf16 -> [rows, Cout] (Cout/2 with act=2, GEGLU)."""
+           rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+           emit_stats: bool = False):
+    """Row-matrix convenience over conv(): x2d [rows, >=Cin] bf16 -> [rows, Cout] (Cout/2 with act=2, GEGLU); with
+    emit_stats (tensor, stats-or-None) as conv()."""
     rows = x2d.shape[0]
     xa = Act(x2d, 1, rows, 1, Cin)
     ra = Act(res1, 1, rows, 1, Cout) if res1 is not None else None
-    return conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale, act=act, rowstat=rowstat, colsum=colsum).t
+    r = conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale, act=act, rowstat=rowstat, colsum=colsum, ln_eps=ln_eps,
+             emit_stats=emit_stats)
+    return (r[0].t, r[1]) if emit_stats else r.t
 
 
 def row_stats(x2d: torch.Tensor, Cc: int, eps: float = 1e-5) -> torch.Tensor:

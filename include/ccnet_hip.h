@@ -84,7 +84,23 @@ typedef struct ccnet_conv_params {
      * Needs R = 1, one source, no rowvec, batch 1; never runs split along K. */
     const float* rowstat; /* fp32 [M][2] or NULL */
     const float* colsum;  /* fp32 [Cout] or NULL */
+    /* rowstat_parts > 0: rowstat is instead fp32 [M][rowstat_parts][2] = (mean, M2) of that many equal column spans of
+     * every row of x1, as the producing layer wrote them through stat_out (below); the kernel merges them (Chan) and uses
+     * rstd = 1 / sqrt(M2 / C1 + ln_eps).  0: rowstat is the final {mean, rstd}. */
+    int32_t rowstat_parts;
+    float ln_eps;
+    /* stat_out != NULL: also write (mean, M2) of every span of ccnet_conv_stat_parts(p) equal column spans of every OUTPUT
+     * row (of `out`, after bias / activation / scale / res1), fp32 [M][parts][2] -- the statistics of the LayerNorm that
+     * follows this layer (BasicTransformerBlock: proj_in -> norm1, attn1.to_out + x -> norm2, attn2.to_out + x -> norm3),
+     * taken in the epilogue so that LayerNorm needs no pass of its own.  Only plans for which ccnet_conv_stat_parts
+     * returns > 0 can do this; others return CCNET_EUNSUP. */
+    float* stat_out;
 } ccnet_conv_params;
+
+/* Number of column spans per row that ccnet_conv_gemm_bf16 would write through stat_out for these parameters (the planned
+ * tile's wave width divides Cout, the plan is not split along K, no GEGLU), or 0 if this plan cannot emit row statistics
+ * (the caller then runs ccnet_row_stats_bf16 on the output). */
+int ccnet_conv_stat_parts(const ccnet_conv_params* p /*host*/);
 
 int ccnet_conv_gemm_bf16(const ccnet_conv_params* p /*host*/, void* stream);
 /* Deep-K layers with few output tiles are split along K (partial sums in `workspace`, summed in slice order by a second

@@ -256,7 +256,7 @@ def test_cabi_exports_every_declared_symbol():
     assert l.ccnet_arch().decode() == "gfx950" and l.ccnet_version() >= 1
     assert l.ccnet_strerror(-1).decode().startswith("invalid")
     import ctypes
-    assert ctypes.sizeof(lib.ConvParams) == 9 * 8 + 23 * 4 + 4 + 3 * 8 + 16 + 16  # struct layout of ccnet_conv_params
+    assert ctypes.sizeof(lib.ConvParams) == 9 * 8 + 23 * 4 + 4 + 3 * 8 + 16 + 16 + 8 + 8  # struct layout of ccnet_conv_params
 
 
 # ------------------------------------------------------------------ sharding (world_size 2, gloo)

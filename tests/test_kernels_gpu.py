@@ -259,6 +259,46 @@ def test_layernorm_folded_into_linear(cuda, rows, C, N, geglu):
     _close(out.float(), two.float(), atol=5e-2, what="folded vs LayerNorm kernel + linear")
 
 
+@pytest.mark.parametrize("rows,C,with_res,expect_parts", [(70000, 320, False, 2), (70000, 320, True, 2), (32768, 640, True, 4),
+                                                          (8192, 1280, False, 8), (8192, 1280, True, 8), (300, 320, True, 0)])
+def test_row_statistics_from_the_producing_layer(cuda, rows, C, with_res, expect_parts):
+    """ccnet_conv_gemm_bf16(stat_out): the (mean, M2) partials that a layer's epilogue writes for the LayerNorm that follows
+    it (proj_in -> norm1, to_out + x -> norm2 / norm3 of a BasicTransformerBlock) against the statistics of its own bf16
+    output, and the next GEMM consuming them (rowstat_parts) against LayerNorm kernel + linear.  Rows with large means; the
+    last case has no statistics instance for its plan and must say so (None) instead of failing."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5 + rows + C)
+    x = (torch.randn(rows, C, generator=g)).to(torch.bfloat16).to(cuda)
+    w = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(torch.bfloat16).to(cuda)
+    b = (0.5 * torch.randn(C, generator=g) + 2.0).to(cuda)  # a row mean well away from zero
+    res = ((torch.randn(rows, C, generator=g) * (0.2 + 3.0 * torch.rand(rows, 1, generator=g))
+            + 3.0 * torch.randn(rows, 1, generator=g)).to(torch.bfloat16).to(cuda)) if with_res else None
+    out, st = ops.linear(x, w, b, C, C, res1=res, emit_stats=True)
+    plain = ops.linear(x, w, b, C, C, res1=res)
+    assert torch.equal(out, plain), "the statistics instance must write the same output as the plain one"
+    if expect_parts == 0:
+        assert st is None
+        return
+    assert st is not None and tuple(st.shape) == (rows, expect_parts, 2)
+    of = out.float()
+    span = C // expect_parts
+    mean = st[:, :, 0].mean(1)
+    m2 = st[:, :, 1].sum(1) + span * ((st[:, :, 0] - mean[:, None]) ** 2).sum(1)
+    var = m2 / C
+    # statistics are taken from the fp32 values on their way out: they differ from those of the rounded output by the
+    # rounding noise only (measured: mean within 5e-3 at |x| up to 20, variance within 0.9 % on the worst of 70000 rows)
+    assert (mean - of.mean(1)).abs().max().item() < 1e-2
+    assert ((var - of.var(1, unbiased=False)).abs() / of.var(1, unbiased=False)).max().item() < 2e-2
+    gamma, beta = (1.0 + 0.2 * torch.randn(C, generator=g)), 0.3 * torch.randn(C, generator=g)
+    w2 = torch.randn(2 * C, C, generator=g) / math.sqrt(C)
+    wf, bf, cs = ops.fold_layernorm(w2, None, gamma, beta)
+    got = ops.linear(out, wf.to(cuda), bf.to(cuda), 2 * C, C, rowstat=st, colsum=cs.to(cuda))
+    ref = F.linear(F.layer_norm(of, (C,), gamma.to(cuda), beta.to(cuda), 1e-5), w2.to(cuda))
+    _close(got.float(), ref, atol=3e-2, what=f"producer statistics -> folded LayerNorm {rows}x{C}")
+    two = ops.linear(ops.layernorm(out, C, gamma.to(cuda), beta.to(cuda)), w2.to(torch.bfloat16).to(cuda), None, 2 * C, C)
+    _close(got.float(), two.float(), atol=5e-2, what="producer statistics vs LayerNorm kernel + linear")
+
+
 def test_geglu(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(41)
