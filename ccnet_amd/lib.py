@@ -23,6 +23,10 @@ EXPORTS = [
     "ccnet_set_option", "ccnet_prof_shapes", "ccnet_conv_workspace_bytes", "ccnet_transpose_pad_bf16",
     "ccnet_attention_d64_causal_bf16", "ccnet_embed_tokens_bf16", "ccnet_gelu_bf16", "ccnet_conv_gemm_bf16_noalloc",
     "ccnet_row_stats_bf16", "ccnet_conv_stat_parts",
+    # training step (backward kernels)
+    "ccnet_im2col_t_bf16", "ccnet_im2col_t_nchw_f32", "ccnet_colsum_bf16", "ccnet_groupnorm_bwd_bf16",
+    "ccnet_layernorm_bwd_bf16", "ccnet_softmax_bwd_rows_bf16", "ccnet_geglu_bwd_bf16", "ccnet_silu_bf16", "ccnet_axpby_bf16",
+    "ccnet_resample_bwd_bf16",
 ]
 
 
@@ -97,6 +101,17 @@ def load() -> C.CDLL:
     lib.ccnet_prof_enable.argtypes = [i]
     lib.ccnet_prof_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ccnet_prof_shapes.argtypes = [C.POINTER(C.c_double), i]
+    i64 = C.c_int64
+    lib.ccnet_im2col_t_bf16.argtypes = [vp, i, i, vp, i, i, i, i, i, i, i, i, i, i, i, vp, i64, vp]
+    lib.ccnet_im2col_t_nchw_f32.argtypes = [vp, i, i, i, i, i, i, vp, i64, i, vp]
+    lib.ccnet_colsum_bf16.argtypes = [vp, i, i, i, i, vp, i, vp, i, vp, vp, vp]
+    lib.ccnet_groupnorm_bwd_bf16.argtypes = [vp, i, i, vp, i, i, vp, i, i, i, i, f, vp, vp, i, vp, i, vp, i, vp, vp]
+    lib.ccnet_layernorm_bwd_bf16.argtypes = [vp, i, vp, i, i, i, f, vp, vp, i, vp, vp]
+    lib.ccnet_softmax_bwd_rows_bf16.argtypes = [vp, vp, i, i, i, i, f, vp]
+    lib.ccnet_geglu_bwd_bf16.argtypes = [vp, i, vp, i, i, i, vp, i, vp]
+    lib.ccnet_silu_bf16.argtypes = [vp, i, vp, i, i, i, i, vp, i, vp]
+    lib.ccnet_axpby_bf16.argtypes = [vp, i, vp, i, i, i, f, f, vp]
+    lib.ccnet_resample_bwd_bf16.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -245,6 +245,48 @@ int ccnet_prof_collect(double* ms, double* flops, int64_t* launches);
  * count (or a negative code). Call before ccnet_prof_collect, which resets the records. */
 int ccnet_prof_shapes(double* table /*host*/, int max_rows);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Training step of the ControlNet: backward kernels.  Reference: the autograd of
+ * src/python/training/training_functions.py:888-1043 (train_epoch_controlnet: loss.backward() through monai-generative's
+ * ControlNet and the frozen DiffusionModelUNet).  Input gradients of conv / linear layers are ccnet_conv_gemm_bf16 over dY
+ * with transposed, tap-flipped weights; weight gradients are ccnet_conv_gemm_bf16 on [channel][pixel] operands
+ * (dY^T by ccnet_transpose_pad_bf16, im2col(X)^T by ccnet_im2col_t_bf16): out[cout][tap * Cin + cin]. */
+
+/* out[(tap * (C1 + C2) + c)][m] = x[(n, iy, ix) of output pixel m under tap][c] (the forward gather of ccnet_conv_gemm_bf16:
+ * stride, pad, nearest x2 upsample, two-source concat), zeros for padding taps and for M <= m < ldo; ldo % 64 == 0. */
+int ccnet_im2col_t_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2, int N, int Hin, int Win,
+                        int Hout, int Wout, int R, int stride, int pad, int ups, void* out /*bf16 [R*R*(C1+C2)][ldo]*/,
+                        int64_t ldo, void* stream);
+/* the same for the fp32 NCHW input of ccnet_conv_in_small (3x3, pad 1, Cin <= 8): rows 9 * Cin .. rows_pad are zeros */
+int ccnet_im2col_t_nchw_f32(const float* x, int Nsrc, int N, int Cin, int H, int W, int stride, void* out, int64_t ldo,
+                            int rows_pad, void* stream);
+/* Column sums over row segments (bias gradient, per-image time-embedding-row gradient): out[(split * nseg + seg)][c] =
+ * sum over the segment's rows that fall to `split` of y[r][c]; with x / rowstat ({mean, rstd} per row) also out2 = sum of
+ * y * (x - mean) * rstd (LayerNorm gamma gradient).  The caller adds the nsplit partials. */
+int ccnet_colsum_bf16(const void* y, int ldy, int nseg, int rows_per_seg, int C, const void* x, int ldx,
+                      const float* rowstat, int nsplit, float* out, float* out2, void* stream);
+/* Backward of ccnet_groupnorm_bf16 (same operands; statistics recomputed): dx (two sources as in the forward) and, when
+ * dparam != NULL, dparam[n][c] = {dgamma, dbeta} of image n (the caller sums over n). */
+int ccnet_groupnorm_bwd_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2, const void* dy, int lddy,
+                             int N, int HW, int groups, float eps, const float* gamma, const float* beta, int silu,
+                             void* dx1, int lddx1, void* dx2, int lddx2, float* dparam, void* stream);
+/* Backward of ccnet_layernorm_bf16 w.r.t. x; rowstat (optional) receives {mean, rstd} per row for ccnet_colsum_bf16. */
+int ccnet_layernorm_bwd_bf16(const void* x, int ldx, const void* dy, int lddy, int rows, int C, float eps,
+                             const float* gamma, void* dx, int lddx, float* rowstat, void* stream);
+/* Row softmax backward, in place over dp: ds = scale * p * (dp - rowsum(p * dp)); columns [cols, cols_pad) become 0. */
+int ccnet_softmax_bwd_rows_bf16(const void* p, void* dp, int ld, int rows, int cols, int cols_pad, float scale, void* stream);
+/* Backward of ccnet_geglu_bf16: h = (a | g) [rows][2C], dy [rows][C] -> dh = (dy * gelu(g) | dy * a * gelu'(g)). */
+int ccnet_geglu_bwd_bf16(const void* h, int ldh, const void* dy, int lddy, int rows, int C, void* dh, int lddh, void* stream);
+/* mode 0: out = silu(x) (the SiLU the sampler fuses into conv epilogues, unfused so its input survives for the backward);
+ * mode 1: out = dy * silu'(x). */
+int ccnet_silu_bf16(const void* x, int ldx, const void* dy, int lddy, int rows, int C, int mode, void* out, int ldo, void* stream);
+/* a = alpha * a + beta * b over bf16 rows (gradient accumulation where a tensor has two consumers). */
+int ccnet_axpby_bf16(void* a, int lda, const void* b, int ldb, int rows, int C, float alpha, float beta, void* stream);
+/* mode 0: adjoint of the nearest x2 upsample folded into a conv gather: out [N][H][W][C] = 2x2 sums of in [N][2H][2W][C];
+ * mode 1: adjoint of a stride-2 convolution's subsampling: out [N][H][W][C] = in [N][Hs][Ws][C] at the even pixels, else 0. */
+int ccnet_resample_bwd_bf16(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int Hs, int Ws, int C, int mode,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,314 @@
+"""Training step of the ControlNet (reference training_functions.py:888-1043): every backward op of
+ccnet_amd.training against torch autograd of the same op in fp32, then the whole forward + backward of the step against
+autograd over the fp32 oracle networks (identical weights): loss and every ControlNet parameter gradient.
+
+Tolerances: activations and activation gradients are bf16 (as under upstream's autocast), so an op's gradients carry a
+relative error of a few 2^-9 per contraction; the bounds below are rel-L2 per tensor, stated where they are used."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _common import SCHED, TINY, TINY_CE, build_pair, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from ccnet_amd import ops, training
+    from ccnet_amd.ops import Act
+    return ops, training, Act
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _pack_w(w):  # [Cout, Cin, R, R] -> bf16 [Cout, R*R*Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(torch.bfloat16)
+
+
+def _nhwc(t):  # NCHW -> [N*H*W, C]
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+def _nchw(rows, N, H, W):
+    return rows.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+CONV_CASES = [
+    # N, H, C1, C2, Cout, R, stride, ups, res, rowvec, scale
+    (2, 16, 64, 0, 128, 3, 1, 1, False, False, 1.0),
+    (2, 16, 128, 64, 64, 3, 1, 1, True, True, 1.0),
+    (3, 16, 64, 0, 64, 3, 2, 1, False, False, 1.0),
+    (2, 8, 128, 0, 128, 3, 1, 2, False, False, 1.0),
+    (2, 16, 64, 64, 192, 1, 1, 1, True, False, 0.5),
+    (1, 12, 64, 0, 64, 3, 1, 1, False, True, 1.0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward(cuda, case):
+    """Input gradient (forward kernel over dY with transposed, flipped weights; zero-stuffing for stride 2, 2x2 sums for the
+    folded upsample), weight gradient (dY^T x im2col(X)^T), bias and time-embedding-row gradients against autograd of
+    F.conv2d on the same bf16 operands.  Bound: rel-L2 2e-2 per gradient tensor."""
+    ops, tr, Act = _mods()
+    N, H, C1, C2, Cout, R, stride, ups, with_res, with_rv, scale = case
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    Ct = C1 + C2
+    x = _bf(torch.randn(N, Ct, H, H, generator=g)).to(cuda)
+    w = (torch.randn(Cout, Ct, R, R, generator=g) / math.sqrt(Ct * R * R)).to(cuda)
+    b = torch.randn(Cout, generator=g).to(cuda)
+    Ho = (H * ups + 2 * (R // 2) - R) // stride + 1
+    res = _bf(torch.randn(N, Cout, Ho, Ho, generator=g)).to(cuda) if with_res else None
+    rv = torch.randn(N, Cout, generator=g).to(cuda) if with_rv else None
+    dy = _bf(torch.randn(N, Cout, Ho, Ho, generator=g)).to(cuda)
+    # reference
+    xr = x.float().requires_grad_(True)
+    wr = _bf(w).float().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if with_res else None
+    rvr = rv.clone().requires_grad_(True) if with_rv else None
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups == 2 else xr
+    y = F.conv2d(xin, wr, br, stride=stride, padding=R // 2)
+    if with_rv:
+        y = y + rvr[:, :, None, None]
+    y = y * scale
+    if with_res:
+        y = y + rr
+    y.backward(dy.float())
+    # product
+    T = tr.Tape()
+    wparam = torch.nn.Parameter(w.clone())
+    bparam = torch.nn.Parameter(b.clone())
+    rows = _nhwc(x)
+    x1 = tr.Var(Act(rows[:, :C1].contiguous(), N, H, H, C1), True)
+    x2 = tr.Var(Act(rows[:, C1:].contiguous(), N, H, H, C2), True) if C2 else None
+    rvar = tr.Var(Act(_nhwc(res), N, Ho, Ho, Cout), True) if with_res else None
+    drv = torch.zeros(N, Cout, device=cuda) if with_rv else None
+    out = T.conv(x1, _pack_w(w), b, Cout, R=R, stride=stride, ups=ups, x2=x2, rowvec=rv, drowvec=drv, res1=rvar, scale=scale,
+                 params=([(wparam, 0, Cout)], [(bparam, 0, Cout)]))
+    assert rel_l2(_nchw(out.a.t.float(), N, Ho, Ho), y.detach()) < 1e-2
+    out.g = _nhwc(dy)
+    T.backward()
+    dx = torch.cat([x1.g, x2.g], 1) if C2 else x1.g
+    assert rel_l2(_nchw(dx.float(), N, H, H), xr.grad) < 2e-2, "input gradient"
+    assert rel_l2(T.grads[wparam], wr.grad) < 2e-2, "weight gradient"
+    assert rel_l2(T.grads[bparam], br.grad) < 2e-2, "bias gradient"
+    if with_res:
+        assert rel_l2(_nchw(rvar.g.float(), N, Ho, Ho), rr.grad) < 1e-2, "residual gradient"
+    if with_rv:
+        assert rel_l2(drv, rvr.grad) < 2e-2, "time-embedding-row gradient"
+
+
+@pytest.mark.parametrize("N,H,C1,C2,groups,silu", [(2, 16, 64, 0, 32, True), (2, 8, 128, 64, 32, True), (3, 8, 320, 0, 32, False),
+                                                    (1, 16, 64, 64, 32, False)])
+def test_groupnorm_backward(cuda, N, H, C1, C2, groups, silu):
+    """GroupNorm(+SiLU) backward over a two-source concat against autograd of F.group_norm (-> F.silu): dx, dgamma, dbeta.
+    Bound: rel-L2 2e-2."""
+    ops, tr, Act = _mods()
+    g = torch.Generator().manual_seed(N + H + C1 + C2)
+    C = C1 + C2
+    x = _bf(torch.randn(N, C, H, H, generator=g) * 1.5 + 0.5).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(C, generator=g)).to(cuda)
+    dy = _bf(torch.randn(N, C, H, H, generator=g)).to(cuda)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.group_norm(xr, groups, gr, br, 1e-5)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy.float())
+    T = tr.Tape()
+    gp, bp = torch.nn.Parameter(gamma.clone()), torch.nn.Parameter(beta.clone())
+    rows = _nhwc(x)
+    x1 = tr.Var(Act(rows[:, :C1].contiguous(), N, H, H, C1), True)
+    x2 = tr.Var(Act(rows[:, C1:].contiguous(), N, H, H, C2), True) if C2 else None
+    out = T.groupnorm(x1, gamma, beta, groups, 1e-5, silu, x2=x2, params=(gp, bp))
+    out.g = _nhwc(dy)
+    T.backward()
+    dx = torch.cat([x1.g, x2.g], 1) if C2 else x1.g
+    assert rel_l2(_nchw(dx.float(), N, H, H), xr.grad) < 2e-2
+    assert rel_l2(T.grads[gp], gr.grad) < 2e-2
+    assert rel_l2(T.grads[bp], br.grad) < 2e-2
+
+
+@pytest.mark.parametrize("rows,C", [(300, 64), (1000, 320), (513, 1280)])
+def test_layernorm_geglu_silu_backward(cuda, rows, C):
+    """LayerNorm (dx, dgamma, dbeta), GEGLU and SiLU backward against autograd.  Bound: rel-L2 2e-2."""
+    ops, tr, Act = _mods()
+    g = torch.Generator().manual_seed(rows + C)
+    x = _bf(torch.randn(rows, C, generator=g) * 2 + 1).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(C, generator=g)).to(cuda)
+    dy = _bf(torch.randn(rows, C, generator=g)).to(cuda)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy.float())
+    T = tr.Tape()
+    gp, bp = torch.nn.Parameter(gamma.clone()), torch.nn.Parameter(beta.clone())
+    xv = tr._v2d(x, True)
+    out = T.layernorm(xv, gamma, beta, 1e-5, params=(gp, bp))
+    out.g = dy
+    T.backward()
+    assert rel_l2(xv.g, xr.grad) < 2e-2
+    assert rel_l2(T.grads[gp], gr.grad) < 2e-2
+    assert rel_l2(T.grads[bp], br.grad) < 2e-2
+    # GEGLU on [rows, 2 * (C / 2)]
+    h = x
+    hr = h.float().requires_grad_(True)
+    a, gg = hr.chunk(2, dim=-1)
+    dyh = dy[:, :C // 2].contiguous()
+    (a * F.gelu(gg)).backward(dyh.float())
+    T = tr.Tape()
+    hv = tr._v2d(h, True)
+    out = T.geglu(hv)
+    assert rel_l2(out.a.t, (a * F.gelu(gg)).detach()) < 1e-2
+    out.g = dyh
+    T.backward()
+    assert rel_l2(hv.g, hr.grad) < 2e-2
+    # SiLU
+    sr = x.float().requires_grad_(True)
+    F.silu(sr).backward(dy.float())
+    T = tr.Tape()
+    sv = tr._v2d(x, True)
+    out = T.silu(sv)
+    out.g = dy
+    T.backward()
+    assert rel_l2(sv.g, sr.grad) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,T_,S,self_attn", [(2, 2, 64, 64, True), (1, 2, 256, 77, False), (2, 1, 128, 20, False)])
+def test_attention_backward(cuda, B, H, T_, S, self_attn):
+    """dQ, dK, dV of softmax(Q K^T / sqrt(64)) V (recomputed, materialised scores) against autograd of the same product in
+    fp32.  Bound: rel-L2 3e-2 (two bf16 roundings of the probabilities on the way)."""
+    ops, tr, Act = _mods()
+    g = torch.Generator().manual_seed(B + H + T_ + S)
+    inner = 64 * H
+    scale = 1.0 / 8.0
+    if self_attn:
+        qkv = _bf(torch.randn(B * T_, 3 * inner, generator=g)).to(cuda)
+        qv = tr._v2d(qkv, True)
+        kvv, q_off, k_off, v_off = qv, 0, inner, 2 * inner
+        qt, kt, vt = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    else:
+        q = _bf(torch.randn(B * T_, inner, generator=g)).to(cuda)
+        kv = _bf(torch.randn(B * S, 2 * inner, generator=g)).to(cuda)
+        qv, kvv, q_off, k_off, v_off = tr._v2d(q, True), tr._v2d(kv, True), 0, 0, inner
+        qt, kt, vt = q, kv[:, :inner], kv[:, inner:]
+    do = _bf(torch.randn(B * T_, inner, generator=g)).to(cuda)
+
+    def heads(t, L):
+        return t.float().reshape(B, L, H, 64).permute(0, 2, 1, 3)
+    qr, kr, vr = heads(qt, T_).requires_grad_(True), heads(kt, S).requires_grad_(True), heads(vt, S).requires_grad_(True)
+    o = torch.softmax(qr @ kr.transpose(-1, -2) * scale, -1) @ vr
+    o.backward(heads(do, T_))
+    Tp = tr.Tape()
+    out = Tp.attention(qv, q_off, kvv, k_off, v_off, B, H, T_, S, scale)
+    assert rel_l2(heads(out.a.t, T_), o.detach()) < 2e-2
+    out.g = do
+
+    def rows(t, L):
+        return t.permute(0, 2, 1, 3).reshape(B * L, inner)
+    Tp.backward()
+    assert rel_l2(qv.g[:, q_off:q_off + inner], rows(qr.grad, T_)) < 3e-2, "dQ"
+    assert rel_l2(kvv.g[:, k_off:k_off + inner], rows(kr.grad, S)) < 3e-2, "dK"
+    assert rel_l2(kvv.g[:, v_off:v_off + inner], rows(vr.grad, S)) < 3e-2, "dV"
+
+
+def _step_inputs(B, dev, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    e = torch.randn(B, 4, 16, 16, generator=g)
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    cond = torch.rand(B, 1, 128, 128, generator=g) * 2 - 1
+    ctx = torch.randn(B, 77, 64, generator=g) * 0.5
+    acq = torch.rand(B, generator=g) * 900 + 60
+    t = torch.randint(0, 1000, (B,), generator=g)
+    return e, noise, cond, ctx, acq, t
+
+
+@pytest.mark.parametrize("snr_gamma", [None, 5.0])
+def test_controlnet_training_step_against_oracle_autograd(cuda, snr_gamma):
+    """train_epoch_controlnet's step body (training_functions.py:930-1018: add_noise, ControlNet, frozen UNet with the residuals,
+    v-prediction target, (SNR-weighted) MSE, backward) on a tiny geometry with text + acquisition-time conditioning: loss and
+    the gradient of every ControlNet parameter against torch autograd over the fp32 oracle networks holding the same weights.
+    Bounds: loss within 2 %; whole-gradient cosine >= 0.995; per-parameter rel-L2 <= 0.15 for every tensor that carries at
+    least 0.1 % of the gradient's norm (bf16 activations through ~40 layers; smaller tensors are rounding noise)."""
+    import oracle.schedulers as osch
+    from ccnet_amd import schedulers as psch
+    from ccnet_amd import training
+    B = 2
+    cfg = dict(TINY, **TINY_CE)
+    cn, ocn = build_pair("controlnet", cfg, 11, cuda, acq=True)
+    un, oun = build_pair("unet", TINY, 12, cuda, acq=True)
+    e, noise, cond, ctx, acq, t = _step_inputs(B, cuda)
+    sch = psch.DDPMScheduler(**SCHED)
+    osc = osch.DDPMScheduler(**SCHED)
+    loss, grads = training.controlnet_loss_and_grads(cn, un, sch, e.to(cuda), noise.to(cuda), t.to(cuda), cond.to(cuda),
+                                                     ctx.to(cuda), acq.to(cuda).unsqueeze(0), 1.0, snr_gamma)
+    # oracle: same step with autograd (fp32, CPU)
+    for p in oun.parameters():
+        p.requires_grad_(False)
+    ocn.train(False)
+    noisy = osc.add_noise(original_samples=e, noise=noise, timesteps=t)
+    cl = acq.reshape(B, 1)
+    down, mid = ocn(noisy, t, cond, 1.0, ctx, cl)
+    pred = oun(noisy, t, ctx, cl, down, mid)
+    target = osc.get_velocity(e, noise, t)
+    if snr_gamma is None:
+        oloss = F.mse_loss(pred.float(), target.float())
+    else:
+        ac = osc.alphas_cumprod[t].float()
+        snr = ac / (1 - ac)
+        wts = torch.minimum(snr, torch.full_like(snr, snr_gamma)) / (snr + 1)
+        oloss = (F.mse_loss(pred.float(), target.float(), reduction="none").mean(dim=[1, 2, 3]) * wts).mean()
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) <= 0.02 * abs(oloss.item()), (loss.item(), oloss.item())
+    pnames = dict(cn.named_parameters())
+    onames = dict(ocn.named_parameters())
+    assert set(pnames) == set(onames)
+    tot = math.sqrt(sum(float(p.grad.norm()) ** 2 for p in onames.values() if p.grad is not None))
+    dot = na = nb = 0.0
+    worst = (0.0, "")
+    missing = []
+    for name, op in onames.items():
+        if op.grad is None:
+            continue
+        gp = grads.get(pnames[name])
+        if gp is None:
+            missing.append(name)
+            continue
+        a, b = gp.float().cpu().reshape(-1), op.grad.float().reshape(-1)
+        dot += float(a @ b); na += float(a @ a); nb += float(b @ b)
+        if float(b.norm()) >= 1e-3 * tot:
+            r = float((a - b).norm() / b.norm())
+            if r > worst[0]:
+                worst = (r, name)
+    assert not missing, f"parameters without a gradient: {missing[:8]}"
+    cos = dot / math.sqrt(na * nb)
+    print(f"loss {loss.item():.6f} vs {oloss.item():.6f}; gradient cosine {cos:.5f}; worst rel-L2 {worst[0]:.4f} ({worst[1]})")
+    assert cos >= 0.995, cos
+    assert worst[0] <= 0.15, worst
+
+
+def test_train_step_reduces_the_loss(cuda):
+    """train_step (zero_grad, forward, backward, clip, AdamW step, re-pack) run three times on one batch: the loss goes down and
+    the sampler's forward sees the updated weights."""
+    from ccnet_amd import schedulers as psch
+    from ccnet_amd import training
+    B = 2
+    cfg = dict(TINY, **TINY_CE)
+    cn, _ = build_pair("controlnet", cfg, 21, cuda, acq=True)
+    un, _ = build_pair("unet", TINY, 22, cuda, acq=True)
+    e, noise, cond, ctx, acq, t = (v.to(cuda) for v in _step_inputs(B, cuda, seed=9))
+    sch = psch.DDPMScheduler(**SCHED)
+    opt = torch.optim.AdamW(cn.parameters(), lr=2e-4)
+    before = [p.detach().clone() for p in cn.parameters()]
+    losses = []
+    for _ in range(3):
+        loss, norm = training.train_step(cn, un, sch, opt, e, noise, t, cond, ctx, acq.unsqueeze(0), clip_grad_norm_by=1.0)
+        losses.append(loss.item())
+        assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
+    assert losses[-1] < losses[0], losses
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters()))
