@@ -178,15 +178,26 @@ class Tape:
                         self.add_grad(p, tot[r0:r0 + nr])
             if params is not None:
                 Ct = x.a.C + (x2.a.C if x2 is not None else 0)
-                M = dy.shape[0]
-                Mp = _pad64(M)
-                dyT = _transpose_pad(dy, M, Cout, Mp)
-                xc = torch.empty((R * R * Ct, Mp), dtype=BF16, device=dy.device)
-                _l.check(_l.load().ccnet_im2col_t_bf16(
-                    x.a.t.data_ptr(), x.a.ld, x.a.C, x2.a.t.data_ptr() if x2 is not None else None,
-                    x2.a.ld if x2 is not None else 0, x2.a.C if x2 is not None else 0, x.a.N, x.a.H, x.a.W, y.H, y.W, R,
-                    stride, pad, ups, xc.data_ptr(), Mp, _stream()), "im2col_t")
-                dw = _gemm_nt(dyT, xc, scale=scale).float()  # [Cout, R*R*Ct]
+                # dW = dY^T . im2col(X): both operands in [channel][pixel] layout, images taken in chunks so that the
+                # transposed im2col stays under 1 GiB (the conditioning embedding's first layers live at 512^2)
+                hw_o, hw_i = y.H * y.W, x.a.H * x.a.W
+                per_image = max(R * R * Ct, Cout) * hw_o * 2
+                nchunk = max(1, min(x.a.N, (1 << 30) // per_image))
+                dw = None
+                for n0 in range(0, x.a.N, nchunk):
+                    n1 = min(x.a.N, n0 + nchunk)
+                    M = (n1 - n0) * hw_o
+                    Mp = _pad64(M)
+                    dyT = _transpose_pad(dy[n0 * hw_o:n1 * hw_o], M, Cout, Mp)
+                    xc = torch.empty((R * R * Ct, Mp), dtype=BF16, device=dy.device)
+                    x1t = x.a.t[n0 * hw_i:n1 * hw_i]
+                    x2t = x2.a.t[n0 * hw_i:n1 * hw_i] if x2 is not None else None
+                    _l.check(_l.load().ccnet_im2col_t_bf16(
+                        x1t.data_ptr(), x.a.ld, x.a.C, x2t.data_ptr() if x2t is not None else None,
+                        x2.a.ld if x2 is not None else 0, x2.a.C if x2 is not None else 0, n1 - n0, x.a.H, x.a.W, y.H, y.W, R,
+                        stride, pad, ups, xc.data_ptr(), Mp, _stream()), "im2col_t")
+                    part = _gemm_nt(dyT, xc, scale=scale).float()  # [Cout, R*R*Ct]
+                    dw = part if dw is None else dw + part
                 for p, r0, nr in params[0]:
                     g = dw[r0:r0 + nr]
                     if p.dim() == 4:  # nn.Conv2d weight [co, ci, R, R] <- packed [co_pad][R][R][ci_pad]
@@ -739,3 +750,49 @@ def train_step(controlnet, unet, scheduler, optimizer, e, noise, timesteps, cond
     optimizer.step()
     controlnet._invalidate()
     return loss, norm
+
+
+class Stage1Wrapper(nn.Module):
+    """util.py:1473-1492: the frozen stage 1 as the training loop calls it -- images -> a sampled latent z = mu + sigma * eps
+    (`stack_input_to_rgb` is the diffusers SD-VAE branch: grey images stacked to three channels, posterior sample)."""
+
+    def __init__(self, model: nn.Module, stack_input_to_rgb: bool = False) -> None:
+        super().__init__()
+        self.model = model
+        self.stack_input_to_rgb = stack_input_to_rgb
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[1] == 1 and self.stack_input_to_rgb:
+            x = torch.cat((x, x, x), dim=1)
+            return self.model.encode(x).latent_dist.sample()
+        z_mu, z_sigma = self.model.encode(x)
+        return self.model.sampling(z_mu, z_sigma)
+
+
+def train_epoch_controlnet(controlnet, diffusion, stage1, scheduler, text_encoder, loader, optimizer, device, epoch: int = 0,
+                           writer=None, scaler=None, scale_factor: float = 1.0, cond_on_acq_times: bool = False,
+                           clip_grad_norm_by: Optional[float] = None, clip_grad_norm_or_value: str = "norm",
+                           controlnet_conditioning_scale: float = 1.0, snr_gamma: Optional[float] = None, lr_scheduler=None):
+    """training_functions.py:888-1043 with the same arguments (drop-in for the reference's loop; `writer` and `scaler` are
+    accepted and unused: there is no fp16 loss scaling on this path -- activations are bf16 -- and sample logging is the
+    sampler's `preview_controlnet_sample`).  Batches are dicts with the reference's keys (training_functions.py:18-23).
+    Returns the list of per-step losses."""
+    if clip_grad_norm_or_value != "norm":
+        raise NotImplementedError("clip_grad_norm_or_value: only 'norm' (the reference's default)")
+    losses = []
+    for x in loader:
+        images = x["target"].to(device)
+        reports = x["report"].to(device)
+        cond = x["source"].to(device)
+        acq = x["acquisition_time"].to(device).unsqueeze(0) if cond_on_acq_times else None
+        timesteps = torch.randint(0, scheduler.num_train_timesteps, (images.shape[0],), device=device).long()
+        e = stage1(images) * scale_factor
+        prompt_embeds = text_encoder(reports.squeeze(1))[0]
+        noise = torch.randn_like(e)
+        loss, _ = train_step(controlnet, diffusion, scheduler, optimizer, e, noise, timesteps, cond, prompt_embeds, acq,
+                             controlnet_conditioning_scale, snr_gamma, clip_grad_norm_by)
+        if lr_scheduler is not None:
+            lr_scheduler.step()
+        losses.append(float(loss))
+    return losses

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from _common import SCHED, TINY, TINY_CE, build_pair, rel_l2
+from _common import G1, G1_CE, SCHED, TINY, TINY_CE, build_pair, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -233,8 +233,9 @@ def test_controlnet_training_step_against_oracle_autograd(cuda, snr_gamma):
     """train_epoch_controlnet's step body (training_functions.py:930-1018: add_noise, ControlNet, frozen UNet with the residuals,
     v-prediction target, (SNR-weighted) MSE, backward) on a tiny geometry with text + acquisition-time conditioning: loss and
     the gradient of every ControlNet parameter against torch autograd over the fp32 oracle networks holding the same weights.
-    Bounds: loss within 2 %; whole-gradient cosine >= 0.995; per-parameter rel-L2 <= 0.15 for every tensor that carries at
-    least 0.1 % of the gradient's norm (bf16 activations through ~40 layers; smaller tensors are rounding noise)."""
+    Bounds: loss within 1 %; whole-gradient cosine >= 0.999; per-parameter rel-L2 <= 0.05 for every tensor that carries at
+    least 0.1 % of the gradient's norm (bf16 activations through ~40 layers; smaller tensors are rounding noise).  Measured:
+    loss 1.277419 vs 1.277683, cosine 0.99992, worst tensor 1.8 % (an attention to_k weight)."""
     import oracle.schedulers as osch
     from ccnet_amd import schedulers as psch
     from ccnet_amd import training
@@ -264,7 +265,7 @@ def test_controlnet_training_step_against_oracle_autograd(cuda, snr_gamma):
         wts = torch.minimum(snr, torch.full_like(snr, snr_gamma)) / (snr + 1)
         oloss = (F.mse_loss(pred.float(), target.float(), reduction="none").mean(dim=[1, 2, 3]) * wts).mean()
     oloss.backward()
-    assert abs(loss.item() - oloss.item()) <= 0.02 * abs(oloss.item()), (loss.item(), oloss.item())
+    assert abs(loss.item() - oloss.item()) <= 0.01 * abs(oloss.item()), (loss.item(), oloss.item())
     pnames = dict(cn.named_parameters())
     onames = dict(ocn.named_parameters())
     assert set(pnames) == set(onames)
@@ -288,8 +289,8 @@ def test_controlnet_training_step_against_oracle_autograd(cuda, snr_gamma):
     assert not missing, f"parameters without a gradient: {missing[:8]}"
     cos = dot / math.sqrt(na * nb)
     print(f"loss {loss.item():.6f} vs {oloss.item():.6f}; gradient cosine {cos:.5f}; worst rel-L2 {worst[0]:.4f} ({worst[1]})")
-    assert cos >= 0.995, cos
-    assert worst[0] <= 0.15, worst
+    assert cos >= 0.999, cos
+    assert worst[0] <= 0.05, worst
 
 
 def test_train_step_reduces_the_loss(cuda):
@@ -312,3 +313,102 @@ def test_train_step_reduces_the_loss(cuda):
         assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
     assert losses[-1] < losses[0], losses
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters()))
+
+
+def test_train_epoch_controlnet_signature(cuda):
+    """train_epoch_controlnet with the reference's arguments and batch keys (training_functions.py:888-920) over two batches,
+    stage 1 through Stage1Wrapper (util.py:1473-1492): finite losses, parameters move."""
+    from ccnet_amd import schedulers as psch
+    from ccnet_amd import training
+    from _common import TINY_VAE
+    cfg = dict(TINY, **TINY_CE)
+    cn, _ = build_pair("controlnet", cfg, 31, cuda, acq=True)
+    un, _ = build_pair("unet", TINY, 32, cuda, acq=True)
+    vae, _ = build_pair("vae", TINY_VAE, 33, cuda)
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn(2, 77, 64, generator=g).to(cuda) * 0.5
+
+    class Text:  # text_encoder(ids)[0] -> [B, 77, D]
+        def __call__(self, ids):
+            return (ctx[: ids.shape[0]],)
+    loader = [{"target": torch.rand(2, 1, 128, 128, generator=g) * 2 - 1, "source": torch.rand(2, 1, 128, 128, generator=g) * 2 - 1,
+               "report": torch.zeros(2, 1, 77, dtype=torch.long), "report_raw": ["", ""],
+               "acquisition_time": torch.rand(2, generator=g) * 900 + 60} for _ in range(2)]
+    opt = torch.optim.AdamW(cn.parameters(), lr=1e-4)
+    before = [p.detach().clone() for p in cn.parameters()]
+    torch.manual_seed(5)
+    losses = training.train_epoch_controlnet(cn, un, training.Stage1Wrapper(vae), psch.DDPMScheduler(**SCHED), Text(), loader, opt,
+                                             cuda, 0, None, None, scale_factor=0.3, cond_on_acq_times=True, clip_grad_norm_by=1.0,
+                                             snr_gamma=5.0)
+    assert len(losses) == 2 and all(math.isfinite(v) for v in losses)
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters()))
+
+
+@pytest.mark.timeout(900)
+def test_controlnet_training_step_at_the_real_geometry(cuda):
+    """The same step at the SD-2.1-base geometry (G1: 320/640/1280/1280 channels, 64x64 latent, 77 x 1024 text, acquisition
+    time; batch 1): loss and the ControlNet's 340 parameter gradients against autograd over the fp32 oracle on the host cores.
+    Bounds as at the tiny geometry: loss within 1 %, whole-gradient cosine >= 0.999, per-parameter rel-L2 <= 0.05 for every
+    tensor that carries >= 0.1 % of the gradient norm.  Measured: loss 1.312219 vs 1.311965, cosine 0.99997, worst tensor
+    1.6 % (a ff.linear1 weight at the 16x16 level)."""
+    import json
+    import os
+    import oracle.schedulers as osch
+    from ccnet_amd import schedulers as psch
+    from ccnet_amd import training
+    from ccnet_amd.synthetic import make_batch
+    cn, ocn = build_pair("controlnet", {**G1, **G1_CE}, 101, cuda, acq=True)
+    un, oun = build_pair("unet", G1, 102, cuda, acq=True)
+    b = make_batch([0], seed=42, acq=True)
+    g = torch.Generator().manual_seed(77)
+    e = torch.randn(1, 4, 64, 64, generator=g)
+    noise, cond, ctx, acq = b["noise"], b["cond"], b["prompt_embeds"], b["acquisition_time"]
+    t = torch.tensor([437])
+    sch, osc = psch.DDPMScheduler(**SCHED), osch.DDPMScheduler(**SCHED)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss, grads = training.controlnet_loss_and_grads(cn, un, sch, e.to(cuda), noise.to(cuda), t.to(cuda), cond.to(cuda),
+                                                     ctx.to(cuda), acq.to(cuda).reshape(1, 1), 1.0, None)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t0
+    for p in oun.parameters():
+        p.requires_grad_(False)
+    noisy = osc.add_noise(original_samples=e, noise=noise, timesteps=t)
+    cl = acq.reshape(1, 1)
+    down, mid = ocn(noisy, t, cond, 1.0, ctx, cl)
+    pred = oun(noisy, t, ctx, cl, down, mid)
+    oloss = F.mse_loss(pred.float(), osc.get_velocity(e, noise, t).float())
+    oloss.backward()
+    pn, on_ = dict(cn.named_parameters()), dict(ocn.named_parameters())
+    tot = math.sqrt(sum(float(p.grad.norm()) ** 2 for p in on_.values() if p.grad is not None))
+    dot = na = nb = 0.0
+    worst, missing = (0.0, ""), []
+    for name, op in on_.items():
+        if op.grad is None:
+            continue
+        gp = grads.get(pn[name])
+        if gp is None:
+            missing.append(name)
+            continue
+        a, bb = gp.float().cpu().reshape(-1), op.grad.float().reshape(-1)
+        dot += float(a @ bb); na += float(a @ a); nb += float(bb @ bb)
+        if float(bb.norm()) >= 1e-3 * tot:
+            r = float((a - bb).norm() / bb.norm())
+            if r > worst[0]:
+                worst = (r, name)
+    cos = dot / math.sqrt(na * nb)
+    rep = {"loss": loss.item(), "oracle_loss": oloss.item(), "gradient_cosine": cos, "worst_rel_l2": worst[0], "worst_tensor": worst[1],
+           "parameters": len(on_), "first_call_seconds": t_first}
+    print(rep)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r2_g1_training_parity.json"), "w") as fh:
+            json.dump(rep, fh)
+    except OSError:
+        pass
+    assert not missing, missing[:8]
+    assert abs(loss.item() - oloss.item()) <= 0.01 * abs(oloss.item())
+    assert cos >= 0.999, cos
+    assert worst[0] <= 0.05, worst
