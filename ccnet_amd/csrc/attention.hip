@@ -26,6 +26,11 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo, B, H, Sq, Skv;
     float scale_log2e;
     unsigned k_bytes, v_bytes;
+    float* lse;  // optional [B][H][Sq]: log2 of the softmax denominator in the scaled log2 domain (training: the backward's P)
+    // backward passes only
+    const __bf16* dO; __bf16* dQ; __bf16* dK; __bf16* dV; const float* delta;
+    int lddo, lddq, lddk, lddv;
+    float scale;
 };
 
 __device__ __forceinline__ s16x4 ds_read_tr16(const char* p) {
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + l31;
+    if (a.lse && hh == 0 && qrow < a.Sq) a.lse[((long long)b * a.H + h) * a.Sq + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
     if (qrow < a.Sq) {
         __bf16* op = a.O + ((long long)b * a.Sq + qrow) * a.ldo + h * 64;
 #pragma unroll
@@ -214,6 +220,316 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
                 v[0] = pack_bf16x2(o[d][4 * q] * inv, o[d][4 * q + 1] * inv);
                 v[1] = pack_bf16x2(o[d][4 * q + 2] * inv, o[d][4 * q + 3] * inv);
                 *(u32x2*)(op + d * 32 + 8 * q + 4 * hh) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------ attention backward (training), head dim 64
+// Two passes, each a re-arrangement of the forward kernel, both recomputing P from Q, K and the forward's LSE (no N x N
+// tensor in memory, no atomics: every gradient element is written by exactly one lane, so the step is bit-reproducible):
+//   * attn_bwd_dq_kernel  -- the query on the lane, exactly the forward's layout: S^T = K Q^T, dP^T = V dO^T,
+//     dS^T = scale P^T o (dP^T - delta_q) is directly the B operand of dQ^T += K^T dS^T (K^T by transposed LDS reads).
+//   * attn_bwd_dkv_kernel -- the key on the lane (a wave owns 32 keys, the block walks the queries): S = Q K^T, dP = dO V^T
+//     with K^T / V^T fragments held in registers; P and dS (bf16) are directly the B operands of dV^T += dO^T P and
+//     dK^T += Q^T dS (Q^T, dO^T by transposed LDS reads); LSE and delta of the tile's 64 queries ride in LDS.
+// delta_q = sum_d dO[q][d] O[q][d] (attn_delta_kernel).  Tiles that are read both by rows and transposed are staged twice,
+// once per swizzle (the forward's K image and V image).
+
+// delta[b][h][q] = sum over the head's 64 channels of dO * O: a wave per (row, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* O, int ldo, const __bf16* dO, int lddo, int rows, int H, int Sq,
+                                                         float* delta) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long long)rows * H) return;
+    const int row = (int)(item / H), h = (int)(item % H);
+    const float v = bf16_bits_to_f32(*(const unsigned short*)(O + (long long)row * ldo + h * 64 + lane)) *
+                    bf16_bits_to_f32(*(const unsigned short*)(dO + (long long)row * lddo + h * 64 + lane));
+    const float s = wave_sum(v);
+    if (lane == 0) delta[((long long)(row / Sq) * H + h) * Sq + (row % Sq)] = s;
+}
+
+__global__ __launch_bounds__(AT_THREADS, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];  // per stage: K (row image), K (transposed-read image), V
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = q0 + l31;
+    const bool qok = qrow < a.Sq;
+    bf16x8 qf[4], dof[4];
+    {
+        const __bf16* qp = a.Q + ((long long)b * a.Sq + (qok ? qrow : 0)) * a.ldq + h * 64 + hh * 8;
+        const __bf16* dp = a.dO + ((long long)b * a.Sq + (qok ? qrow : 0)) * a.lddo + h * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 v = *(const u32x4*)(qp + ks * 16), w = *(const u32x4*)(dp + ks * 16);
+            if (!qok) { v = u32x4{0, 0, 0, 0}; w = u32x4{0, 0, 0, 0}; }
+            qf[ks] = __builtin_bit_cast(bf16x8, v);
+            dof[ks] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    const long long sidx = ((long long)b * a.H + h) * a.Sq + (qok ? qrow : 0);
+    const float lse = qok ? a.lse[sidx] : 1e30f, dlt = qok ? a.delta[sidx] : 0.f;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.K + (long long)b * a.Skv * a.ldk + h * 64), 0, a.k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.V + (long long)b * a.Skv * a.ldv + h * 64), 0, a.v_bytes, 0x00020000);
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    u32x4 kr[2], vr[2];
+    auto issue_loads = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = tile * KV_TILE + lrow + i * 32;
+            const bool ok = key < a.Skv;
+            const unsigned ko = ok ? (unsigned)(key * a.ldk + lchunk * 8) * 2u : 0x80000000u;
+            const unsigned vo = ok ? (unsigned)(key * a.ldv + lchunk * 8) * 2u : 0x80000000u;
+            kr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)ko, 0, 0));
+            vr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)vo, 0, 0));
+        }
+    };
+    auto store_stage = [&](int s) {
+        char* kb = smem + s * 3 * TILE_BYTES;
+        char* kt = kb + TILE_BYTES;
+        char* vb = kt + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lrow + i * 32;
+            *(u32x4*)(kb + r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4)) = kr[i];
+            *(u32x4*)(kt + r * 128 + ((lchunk ^ (((r >> 1) & 1) << 2)) << 4)) = kr[i];
+            *(u32x4*)(vb + r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4)) = vr[i];
+        }
+    };
+    f32x16 dq[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+    const int kswz = (l31 >> 1) & 7;
+    const int g16 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int ntiles = (a.Skv + KV_TILE - 1) / KV_TILE;
+    issue_loads(0);
+    store_stage(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) issue_loads(t + 1);
+        const char* kb = smem + (t & 1) * 3 * TILE_BYTES;
+        const char* kt = kb + TILE_BYTES;
+        const char* vb = kt + TILE_BYTES;
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = (kbk * 32 + l31) * 128 + (((2 * ks + hh) ^ kswz) << 4);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kb + off), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vb + off), dof[ks], dp, 0, 0, 0);
+            }
+            const int kbase = t * KV_TILE + kbk * 32 + 4 * hh;
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) {
+                float ds[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 8 * sI + j;
+                    const int key = kbase + (e & 3) + 8 * (e >> 2);
+                    const float p = key < a.Skv ? __builtin_amdgcn_exp2f(fmaf(s[e], a.scale_log2e, -lse)) : 0.f;
+                    ds[j] = a.scale * p * (dp[e] - dlt);
+                }
+                dsf[kbk][sI] = __builtin_bit_cast(bf16x8, pack8(ds));
+            }
+        }
+        // dQ^T[d][q] += K^T[d][key] * dS^T[key][q]
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    const int key0 = kbk * 32 + 16 * sI + 4 * hh;
+                    const int chunk = (d * 32 + g16 * 16 + tp * 4) >> 3;
+                    const int within = ((d * 32 + g16 * 16 + tp * 4) & 7) * 2;
+                    const int r0 = key0 + tq, r1 = key0 + 8 + tq;
+                    const s16x4 lo = ds_read_tr16(kt + r0 * 128 + ((chunk ^ (((r0 >> 1) & 1) << 2)) << 4) + within);
+                    const s16x4 hi = ds_read_tr16(kt + r1 * 128 + ((chunk ^ (((r1 >> 1) & 1) << 2)) << 4) + within);
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), dsf[kbk][sI], dq[d], 0, 0, 0);
+                }
+        if (more) store_stage((t + 1) & 1);
+        __syncthreads();
+    }
+    if (qok) {
+        __bf16* op = a.dQ + ((long long)b * a.Sq + qrow) * a.lddq + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x2 v;
+                v[0] = pack_bf16x2(dq[d][4 * q], dq[d][4 * q + 1]);
+                v[1] = pack_bf16x2(dq[d][4 * q + 2], dq[d][4 * q + 3]);
+                *(u32x2*)(op + d * 32 + 8 * q + 4 * hh) = v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(AT_THREADS, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    // per stage: Q (row image), Q (transposed-read image), dO (row), dO (transposed), then LSE and delta of the tile's 64 queries
+    constexpr int STAGE_B = 4 * TILE_BYTES + 512;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int krow = k0 + l31;
+    const bool kok = krow < a.Skv;
+    bf16x8 kf[4], vf[4];  // K^T / V^T fragments (B operands): lane holds K[krow][16 ks + 8 hh .. +7]
+    {
+        const __bf16* kp = a.K + ((long long)b * a.Skv + (kok ? krow : 0)) * a.ldk + h * 64 + hh * 8;
+        const __bf16* vp = a.V + ((long long)b * a.Skv + (kok ? krow : 0)) * a.ldv + h * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 v = *(const u32x4*)(kp + ks * 16), w = *(const u32x4*)(vp + ks * 16);
+            if (!kok) { v = u32x4{0, 0, 0, 0}; w = u32x4{0, 0, 0, 0}; }
+            kf[ks] = __builtin_bit_cast(bf16x8, v);
+            vf[ks] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Q + (long long)b * a.Sq * a.ldq + h * 64), 0, a.k_bytes, 0x00020000);   // (k_bytes / v_bytes: Q / dO extents here)
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.dO + (long long)b * a.Sq * a.lddo + h * 64), 0, a.v_bytes, 0x00020000);
+    const float* lse_p = a.lse + ((long long)b * a.H + h) * a.Sq;
+    const float* dlt_p = a.delta + ((long long)b * a.H + h) * a.Sq;
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    u32x4 qr[2], dr[2];
+    float st_l = 0.f, st_d = 0.f;
+    auto issue_loads = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tile * KV_TILE + lrow + i * 32;
+            const bool ok = q < a.Sq;
+            const unsigned qo = ok ? (unsigned)(q * a.ldq + lchunk * 8) * 2u : 0x80000000u;
+            const unsigned dofs = ok ? (unsigned)(q * a.lddo + lchunk * 8) * 2u : 0x80000000u;
+            qr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, (int)qo, 0, 0));
+            dr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)dofs, 0, 0));
+        }
+        if (tid < 64) {  // a query beyond Sq gets P = exp2(-1e30) = 0
+            const int q = tile * KV_TILE + tid;
+            st_l = q < a.Sq ? lse_p[q] : 1e30f;
+            st_d = q < a.Sq ? dlt_p[q] : 0.f;
+        }
+    };
+    auto store_stage = [&](int s) {
+        char* qb = smem + s * STAGE_B;
+        char* qt = qb + TILE_BYTES;
+        char* db = qt + TILE_BYTES;
+        char* dt = db + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lrow + i * 32;
+            const int orow = r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4), otr = r * 128 + ((lchunk ^ (((r >> 1) & 1) << 2)) << 4);
+            *(u32x4*)(qb + orow) = qr[i];
+            *(u32x4*)(qt + otr) = qr[i];
+            *(u32x4*)(db + orow) = dr[i];
+            *(u32x4*)(dt + otr) = dr[i];
+        }
+        if (tid < 64) {
+            float* f = (float*)(dt + TILE_BYTES);
+            f[tid] = st_l;
+            f[64 + tid] = st_d;
+        }
+    };
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+    const int swz = (l31 >> 1) & 7;
+    const int g16 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int ntiles = (a.Sq + KV_TILE - 1) / KV_TILE;
+    issue_loads(0);
+    store_stage(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) issue_loads(t + 1);
+        const char* qb = smem + (t & 1) * STAGE_B;
+        const char* qt = qb + TILE_BYTES;
+        const char* db = qt + TILE_BYTES;
+        const char* dt = db + TILE_BYTES;
+        const float* stat = (const float*)(dt + TILE_BYTES);
+#pragma unroll
+        for (int qbk = 0; qbk < 2; ++qbk) {
+            // S[q][key] and dP[q][key] of 32 queries x this wave's 32 keys: accumulator register e is query
+            // qbk * 32 + (e & 3) + 8 (e >> 2) + 4 hh of the tile, the lane is the key
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = (qbk * 32 + l31) * 128 + (((2 * ks + hh) ^ swz) << 4);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qb + off), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(db + off), vf[ks], dp, 0, 0, 0);
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) {
+                float p[8], ds[8];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int qo = qbk * 32 + 16 * sI + 8 * g + 4 * hh;  // 4 consecutive queries: registers 8 sI + 4 g .. + 3
+                    const f32x4 l4 = *(const f32x4*)(stat + qo), d4 = *(const f32x4*)(stat + 64 + qo);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 8 * sI + 4 * g + j;
+                        p[4 * g + j] = __builtin_amdgcn_exp2f(fmaf(s[e], a.scale_log2e, -l4[j]));
+                        ds[4 * g + j] = a.scale * p[4 * g + j] * (dp[e] - d4[j]);
+                    }
+                }
+                pf[sI] = __builtin_bit_cast(bf16x8, pack8(p));
+                dsf[sI] = __builtin_bit_cast(bf16x8, pack8(ds));
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    const int qq0 = qbk * 32 + 16 * sI + 4 * hh;
+                    const int chunk = (d * 32 + g16 * 16 + tp * 4) >> 3;
+                    const int within = ((d * 32 + g16 * 16 + tp * 4) & 7) * 2;
+                    const int r0 = qq0 + tq, r1 = qq0 + 8 + tq;
+                    const int o0 = r0 * 128 + ((chunk ^ (((r0 >> 1) & 1) << 2)) << 4) + within;
+                    const int o1 = r1 * 128 + ((chunk ^ (((r1 >> 1) & 1) << 2)) << 4) + within;
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x4 lo = ds_read_tr16(dt + o0), hi = ds_read_tr16(dt + o1);
+                    s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[sI], dv[d], 0, 0, 0);
+                    lo = ds_read_tr16(qt + o0); hi = ds_read_tr16(qt + o1);
+                    vv = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), dsf[sI], dk[d], 0, 0, 0);
+                }
+        }
+        if (more) store_stage((t + 1) & 1);
+        __syncthreads();
+    }
+    if (kok) {
+        __bf16* kp = a.dK + ((long long)b * a.Skv + krow) * a.lddk + h * 64;
+        __bf16* vp = a.dV + ((long long)b * a.Skv + krow) * a.lddv + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x2 v;
+                v[0] = pack_bf16x2(dk[d][4 * q], dk[d][4 * q + 1]);
+                v[1] = pack_bf16x2(dk[d][4 * q + 2], dk[d][4 * q + 3]);
+                *(u32x2*)(kp + d * 32 + 8 * q + 4 * hh) = v;
+                v[0] = pack_bf16x2(dv[d][4 * q], dv[d][4 * q + 1]);
+                v[1] = pack_bf16x2(dv[d][4 * q + 2], dv[d][4 * q + 3]);
+                *(u32x2*)(vp + d * 32 + 8 * q + 4 * hh) = v;
             }
     }
 }
@@ -263,7 +579,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const __bf16* x, int
 
 namespace {
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H,
-                     int Sq, int Skv, float scale, bool causal, void* stream) {
+                     int Sq, int Skv, float scale, bool causal, void* stream, float* lse = nullptr) {
     if (!Q || !K || !V || !O) return CCNET_EINVAL;
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return CCNET_EINVAL;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4)) return CCNET_EINVAL;
@@ -276,6 +592,7 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv;
     a.scale_log2e = scale * 1.4426950408889634f;
     a.k_bytes = (unsigned)kb; a.v_bytes = (unsigned)vb;
+    a.lse = lse;
     if (causal)
         hipLaunchKernelGGL(attn_d64_kernel<true>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     else
@@ -288,6 +605,48 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
 extern "C" int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                                         void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream) {
     return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, scale, false, stream);
+}
+
+extern "C" int ccnet_attention_d64_lse_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                                            int B, int H, int Sq, int Skv, float scale, float* lse, void* stream) {
+    if (!lse) return CCNET_EINVAL;
+    return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, scale, false, stream, lse);
+}
+
+extern "C" int ccnet_attention_d64_bwd_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                                            int ldo, const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq,
+                                            void* dK, int lddk, void* dV, int lddv, int B, int H, int Sq, int Skv, float scale,
+                                            void* stream) {
+    if (!Q || !K || !V || !O || !dO || !lse || !delta) return CCNET_EINVAL;
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || B > 65535 || H > 65535) return CCNET_EINVAL;
+    if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (lddo % 8) || (dQ && (lddq % 4)) || (dK && (lddk % 4)) || (dV && (lddv % 4)))
+        return CCNET_EINVAL;
+    if ((dK == nullptr) != (dV == nullptr)) return CCNET_EINVAL;
+    const long long kb = ((long long)Skv - 1) * ldk * 2 + 128, vb = ((long long)Skv - 1) * ldv * 2 + 128;
+    const long long qb = ((long long)Sq - 1) * ldq * 2 + 128, db = ((long long)Sq - 1) * lddo * 2 + 128;
+    if (kb >= 0x7fffffffLL || vb >= 0x7fffffffLL || qb >= 0x7fffffffLL || db >= 0x7fffffffLL) return CCNET_EUNSUP;
+    hipStream_t st = (hipStream_t)stream;
+    const long long items = (long long)B * Sq * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const __bf16*)O, ldo,
+                       (const __bf16*)dO, lddo, B * Sq, H, Sq, delta);
+    CCNET_LAUNCH_CHECK();
+    AttnArgs a{};
+    a.Q = (const __bf16*)Q; a.K = (const __bf16*)K; a.V = (const __bf16*)V; a.dO = (const __bf16*)dO;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv;
+    a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    a.lse = (float*)lse; a.delta = delta;
+    a.dQ = (__bf16*)dQ; a.lddq = lddq; a.dK = (__bf16*)dK; a.lddk = lddk; a.dV = (__bf16*)dV; a.lddv = lddv;
+    if (dQ) {
+        a.k_bytes = (unsigned)kb; a.v_bytes = (unsigned)vb;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, st, a);
+        CCNET_LAUNCH_CHECK();
+    }
+    if (dK) {
+        a.k_bytes = (unsigned)qb; a.v_bytes = (unsigned)db;  // the staged tensors of this pass are Q and dO
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Skv + 127) / 128, H, B), dim3(AT_THREADS), 0, st, a);
+        CCNET_LAUNCH_CHECK();
+    }
+    return CCNET_OK;
 }
 
 extern "C" int ccnet_attention_d64_causal_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,

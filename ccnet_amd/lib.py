@@ -26,7 +26,7 @@ EXPORTS = [
     # training step (backward kernels)
     "ccnet_im2col_t_bf16", "ccnet_im2col_t_nchw_f32", "ccnet_colsum_bf16", "ccnet_groupnorm_bwd_bf16",
     "ccnet_layernorm_bwd_bf16", "ccnet_softmax_bwd_rows_bf16", "ccnet_geglu_bwd_bf16", "ccnet_silu_bf16", "ccnet_axpby_bf16",
-    "ccnet_resample_bwd_bf16",
+    "ccnet_resample_bwd_bf16", "ccnet_attention_d64_lse_bf16", "ccnet_attention_d64_bwd_bf16",
 ]
 
 
@@ -112,6 +112,8 @@ def load() -> C.CDLL:
     lib.ccnet_silu_bf16.argtypes = [vp, i, vp, i, i, i, i, vp, i, vp]
     lib.ccnet_axpby_bf16.argtypes = [vp, i, vp, i, i, i, f, f, vp]
     lib.ccnet_resample_bwd_bf16.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, vp]
+    lib.ccnet_attention_d64_lse_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, vp, vp]
+    lib.ccnet_attention_d64_bwd_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, i, i, f, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -337,13 +337,19 @@ class Tape:
     # ---- attention (head dim 64)
     def attention(self, q: Var, q_off: int, kv: Var, k_off: int, v_off: int, B: int, H: int, T: int, S: int, scale: float) -> Var:
         """softmax(scale Q K^T) V per (image, head); q = q.a.t[:, q_off : q_off + 64 H] ([B*T] rows), k / v columns of
-        kv.a.t ([B*S] rows).  Forward: the flash kernel.  Backward: per head, batched over the images -- scores and
-        probabilities are recomputed and materialised (bf16), dP = dO V^T, dS = scale P o (dP - rowsum(P o dP)),
-        dQ = dS K, dK = dS^T Q, dV = P^T dO, all on the implicit-GEMM kernel."""
+        kv.a.t ([B*S] rows).  Forward: the flash kernel, keeping the row log-sum-exp.  Backward: ccnet_attention_d64_bwd_bf16
+        (P recomputed tile by tile from Q, K and the log-sum-exp; one pass for dQ, one for dK / dV; written straight into the
+        column slices of the operands' gradient buffers)."""
         d = 64
         inner = H * d
+        lib = _l.load()
         qt, kt, vt = q.a.t[:, q_off:q_off + inner], kv.a.t[:, k_off:k_off + inner], kv.a.t[:, v_off:v_off + inner]
-        o = ops.attention_d64(qt, kt, vt, B, H, T, S, scale)
+        dev = qt.device
+        o = torch.empty((B * T, inner), dtype=BF16, device=dev)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+        _l.check(lib.ccnet_attention_d64_lse_bf16(qt.data_ptr(), qt.stride(0), kt.data_ptr(), kt.stride(0), vt.data_ptr(),
+                                                  vt.stride(0), o.data_ptr(), o.stride(0), B, H, T, S, scale, lse.data_ptr(),
+                                                  _stream()), "attention_d64_lse")
         out = Var(Act(o, q.a.N, q.a.H, q.a.W, inner), q.rg or kv.rg)
         if not out.rg:
             return out
@@ -352,57 +358,18 @@ class Tape:
             do = out.g
             if do is None:
                 return
-            lib = _l.load()
-            dev = do.device
-            Sp, Tp = _pad64(S), _pad64(T)
-            dq_all = q.grad_buf() if q.rg else None
-            dkv_all = kv.grad_buf() if kv.rg else None
-            kp = torch.zeros((B, Sp, d), dtype=BF16, device=dev)
-            vp = torch.zeros((B, Sp, d), dtype=BF16, device=dev)
-            P = torch.empty((B, T, Sp), dtype=BF16, device=dev)
-            dP = torch.empty((B, T, Sp), dtype=BF16, device=dev)
-
-            def bgemm(x, ldx, sx, w, ldw, sw, outt, ldo, so, M, N_, K, sc=1.0):
-                p = _l.ConvParams()
-                p.x1 = x.data_ptr(); p.w = w.data_ptr(); p.out = outt.data_ptr()
-                p.N, p.Hin, p.Win, p.Hout, p.Wout = 1, M, 1, M, 1
-                p.C1 = K; p.C2 = 0; p.Cout = N_; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
-                p.ldx1 = ldx; p.ldw = ldw; p.ldo = ldo; p.scale = sc; p.batch = B
-                p.sx1 = sx; p.sw = sw; p.so = so
-                ops._launch_conv(p, dev, "attention backward GEMM")
-
-            def tpad(x, ldx, rows, cols, sx, rows_pad):  # [B][rows][cols] -> [B][cols][rows_pad]
-                outt = torch.empty((B, cols, rows_pad), dtype=BF16, device=dev)
-                _l.check(lib.ccnet_transpose_pad_bf16(x.data_ptr(), ldx, rows, cols, sx, outt.data_ptr(), rows_pad, rows_pad,
-                                                      cols * rows_pad, B, _stream()), "transpose_pad")
-                return outt
-
-            for h in range(H):
-                qh, kh, vh = qt[:, h * d:(h + 1) * d], kt[:, h * d:(h + 1) * d], vt[:, h * d:(h + 1) * d]
-                doh = do[:, h * d:(h + 1) * d]
-                kp[:, :S].copy_(kh.unflatten(0, (B, S)))
-                vp[:, :S].copy_(vh.unflatten(0, (B, S)))
-                bgemm(qh, qh.stride(0), T * qh.stride(0), kp, d, Sp * d, P, Sp, T * Sp, T, Sp, d, scale)
-                P2 = P.view(B * T, Sp)
-                _l.check(lib.ccnet_softmax_rows_bf16(P2.data_ptr(), Sp, B * T, S, Sp, 1.0, P2.data_ptr(), Sp, _stream()), "softmax")
-                bgemm(doh, doh.stride(0), T * doh.stride(0), vp, d, Sp * d, dP, Sp, T * Sp, T, Sp, d)
-                _l.check(lib.ccnet_softmax_bwd_rows_bf16(P2.data_ptr(), dP.data_ptr(), Sp, B * T, S, Sp, scale, _stream()),
-                         "softmax_bwd")
-                if dq_all is not None:  # dQ = dS . K   (weights = K^T rows [d][Sp])
-                    kT = tpad(kp, d, Sp, d, Sp * d, Sp)
-                    dqh = dq_all[:, q_off + h * d:q_off + (h + 1) * d]
-                    bgemm(dP, Sp, T * Sp, kT, Sp, d * Sp, dqh, dqh.stride(0), T * dqh.stride(0), T, d, Sp)
-                if dkv_all is not None:
-                    dST = tpad(dP, Sp, T, Sp, T * Sp, Tp)   # [B][Sp][Tp]
-                    PT = tpad(P, Sp, T, Sp, T * Sp, Tp)
-                    qT = tpad(qh, qh.stride(0), T, d, T * qh.stride(0), Tp)      # [B][d][Tp]
-                    doT = tpad(doh, doh.stride(0), T, d, T * doh.stride(0), Tp)
-                    dk = torch.empty((B, Sp, d), dtype=BF16, device=dev)
-                    dv = torch.empty((B, Sp, d), dtype=BF16, device=dev)
-                    bgemm(dST, Tp, Sp * Tp, qT, Tp, d * Tp, dk, d, Sp * d, Sp, d, Tp)
-                    bgemm(PT, Tp, Sp * Tp, doT, Tp, d * Tp, dv, d, Sp * d, Sp, d, Tp)
-                    dkv_all[:, k_off + h * d:k_off + (h + 1) * d].unflatten(0, (B, S)).copy_(dk[:, :S])
-                    dkv_all[:, v_off + h * d:v_off + (h + 1) * d].unflatten(0, (B, S)).copy_(dv[:, :S])
+            delta = torch.empty((B, H, T), dtype=torch.float32, device=dev)
+            dq = q.grad_buf()[:, q_off:q_off + inner] if q.rg else None
+            dkv = kv.grad_buf() if kv.rg else None
+            dk = dkv[:, k_off:k_off + inner] if dkv is not None else None
+            dv = dkv[:, v_off:v_off + inner] if dkv is not None else None
+            _l.check(lib.ccnet_attention_d64_bwd_bf16(
+                qt.data_ptr(), qt.stride(0), kt.data_ptr(), kt.stride(0), vt.data_ptr(), vt.stride(0), o.data_ptr(), o.stride(0),
+                do.data_ptr(), do.stride(0), lse.data_ptr(), delta.data_ptr(),
+                dq.data_ptr() if dq is not None else None, dq.stride(0) if dq is not None else 0,
+                dk.data_ptr() if dk is not None else None, dk.stride(0) if dk is not None else 0,
+                dv.data_ptr() if dv is not None else None, dv.stride(0) if dv is not None else 0, B, H, T, S, scale, _stream()),
+                "attention_d64_bwd")
 
         self.steps.append(bw)
         return out

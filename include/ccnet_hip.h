@@ -273,6 +273,15 @@ int ccnet_groupnorm_bwd_bf16(const void* x1, int ldx1, int C1, const void* x2, i
 /* Backward of ccnet_layernorm_bf16 w.r.t. x; rowstat (optional) receives {mean, rstd} per row for ccnet_colsum_bf16. */
 int ccnet_layernorm_bwd_bf16(const void* x, int ldx, const void* dy, int lddy, int rows, int C, float eps,
                              const float* gamma, void* dx, int lddx, float* rowstat, void* stream);
+/* Flash attention (head dim 64) for the training step: the forward with the row log-sum-exp kept (lse[b][h][q], base 2, of the
+ * scaled scores), and its backward -- P is recomputed from Q, K and lse tile by tile (no N x N tensor), dQ by a pass with the
+ * query on the lane, dK / dV by a pass with the key on the lane, no atomics.  delta [B][H][Sq] is scratch the call fills
+ * (rowsum(dO o O)).  dQ, or the pair dK / dV, may be NULL (cross-attention under a frozen projection). */
+int ccnet_attention_d64_lse_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B,
+                                 int H, int Sq, int Skv, float scale, float* lse, void* stream);
+int ccnet_attention_d64_bwd_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo,
+                                 const void* dO, int lddo, const float* lse, float* delta, void* dQ, int lddq, void* dK, int lddk,
+                                 void* dV, int lddv, int B, int H, int Sq, int Skv, float scale, void* stream);
 /* Row softmax backward, in place over dp: ds = scale * p * (dp - rowsum(p * dp)); columns [cols, cols_pad) become 0. */
 int ccnet_softmax_bwd_rows_bf16(const void* p, void* dp, int ld, int rows, int cols, int cols_pad, float scale, void* stream);
 /* Backward of ccnet_geglu_bf16: h = (a | g) [rows][2C], dy [rows][C] -> dh = (dy * gelu(g) | dy * a * gelu'(g)). */

@@ -179,10 +179,11 @@ def test_layernorm_geglu_silu_backward(cuda, rows, C):
     assert rel_l2(sv.g, sr.grad) < 2e-2
 
 
-@pytest.mark.parametrize("B,H,T_,S,self_attn", [(2, 2, 64, 64, True), (1, 2, 256, 77, False), (2, 1, 128, 20, False)])
+@pytest.mark.parametrize("B,H,T_,S,self_attn", [(2, 2, 64, 64, True), (1, 2, 256, 77, False), (2, 1, 128, 20, False),
+                                                (1, 3, 1000, 1000, True), (2, 5, 4096, 4096, True), (1, 2, 200, 333, False)])
 def test_attention_backward(cuda, B, H, T_, S, self_attn):
-    """dQ, dK, dV of softmax(Q K^T / sqrt(64)) V (recomputed, materialised scores) against autograd of the same product in
-    fp32.  Bound: rel-L2 3e-2 (two bf16 roundings of the probabilities on the way)."""
+    """dQ, dK, dV of softmax(Q K^T / sqrt(64)) V (flash backward: P recomputed tile by tile from the forward's log-sum-exp, ragged
+    query and key tails included) against autograd of the same product in fp32.  Bound: rel-L2 3e-2 (bf16 P and dS operands)."""
     ops, tr, Act = _mods()
     g = torch.Generator().manual_seed(B + H + T_ + S)
     inner = 64 * H
