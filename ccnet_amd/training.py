@@ -82,13 +82,36 @@ def _transpose_pad(x: torch.Tensor, rows: int, cols: int, rows_pad: int) -> torc
     return out
 
 
-def _gemm_nt(a: torch.Tensor, b: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[i][j] = scale * sum_k a[i][k] b[j][k]; a [Ra, K], b [Rb, K] bf16 with K % 64 == 0, Rb % 8 == 0 (row strides free)."""
+def _gemm_nt(a: torch.Tensor, b: torch.Tensor, scale: float = 1.0, nb: int = 1) -> torch.Tensor:
+    """fp32 out[i][j] = scale * sum_k a[i][k] b[j][k]; a [Ra, K], b [Rb, K] bf16 (row strides free), Rb % 8 == 0.  nb > 1: the
+    contraction is cut into nb equal slices of K / nb (a multiple of 64) that run as one batched launch and are summed in fp32
+    -- a weight gradient contracts over up to millions of pixels into a few tiles, far too few for the kernel's own split-K."""
     Ra, K = a.shape
     Rb = b.shape[0]
-    xa = Act(a, 1, Ra, 1, K)
-    oa = Act(out, 1, Ra, 1, Rb) if out is not None else None
-    return ops.conv(xa, b, None, Rb, R=1, pad=0, scale=scale, out=oa).t
+    if nb <= 1:
+        return ops.conv(Act(a, 1, Ra, 1, K), b, None, Rb, R=1, pad=0, scale=scale).t.float()
+    Kc = K // nb
+    out = torch.empty((nb, Ra, Rb), dtype=BF16, device=a.device)
+    p = _l.ConvParams()
+    p.x1 = a.data_ptr(); p.w = b.data_ptr(); p.out = out.data_ptr()
+    p.N, p.Hin, p.Win, p.Hout, p.Wout = 1, Ra, 1, Ra, 1
+    p.C1 = Kc; p.C2 = 0; p.Cout = Rb; p.R = 1; p.stride = 1; p.pad = 0; p.ups = 1
+    p.ldx1 = a.stride(0); p.ldw = b.stride(0); p.ldo = Rb; p.scale = scale; p.batch = nb
+    p.sx1 = Kc; p.sw = Kc; p.so = Ra * Rb
+    ops._launch_conv(p, a.device, "weight-gradient GEMM")
+    return out.float().sum(0)
+
+
+def _plan_wgrad(M: int, Ra: int, Rb: int) -> Tuple[int, int]:
+    """(padded contraction length, slices) for a weight-gradient GEMM [Ra, M] x [Rb, M]^T: enough (tile, slice) pairs to fill
+    the chip, every slice at least 4096 deep."""
+    Mp = _pad64(M)
+    tiles = -(-Ra // 256) * -(-Rb // 256)
+    nb = max(1, min(1024 // tiles, Mp // 4096))
+    if nb <= 1:
+        return Mp, 1
+    Kc = _pad64(-(-Mp // nb))
+    return Kc * nb, nb
 
 
 def _colsum(y: torch.Tensor, nseg: int, x: Optional[torch.Tensor] = None, rowstat: Optional[torch.Tensor] = None):
@@ -187,7 +210,7 @@ class Tape:
                 for n0 in range(0, x.a.N, nchunk):
                     n1 = min(x.a.N, n0 + nchunk)
                     M = (n1 - n0) * hw_o
-                    Mp = _pad64(M)
+                    Mp, nb = _plan_wgrad(M, Cout, R * R * Ct)
                     dyT = _transpose_pad(dy[n0 * hw_o:n1 * hw_o], M, Cout, Mp)
                     xc = torch.empty((R * R * Ct, Mp), dtype=BF16, device=dy.device)
                     x1t = x.a.t[n0 * hw_i:n1 * hw_i]
@@ -196,7 +219,7 @@ class Tape:
                         x1t.data_ptr(), x.a.ld, x.a.C, x2t.data_ptr() if x2t is not None else None,
                         x2.a.ld if x2 is not None else 0, x2.a.C if x2 is not None else 0, n1 - n0, x.a.H, x.a.W, y.H, y.W, R,
                         stride, pad, ups, xc.data_ptr(), Mp, _stream()), "im2col_t")
-                    part = _gemm_nt(dyT, xc, scale=scale).float()  # [Cout, R*R*Ct]
+                    part = _gemm_nt(dyT, xc, scale=scale, nb=nb)  # [Cout, R*R*Ct]
                     dw = part if dw is None else dw + part
                 for p, r0, nr in params[0]:
                     g = dw[r0:r0 + nr]
@@ -487,7 +510,13 @@ def _embedding(T: Tape, nt: _Net, timesteps, class_labels, B: int):
 
     def lin_bw(dy, x, w):  # y = x w^T + b: (dx, dw, db)
         dx = ops.linear_f32(dy, w.t().contiguous(), None)
-        dw = ops.linear_f32(dy.t().contiguous(), x.t().contiguous(), None)
+        # dw = dy^T x contracts over the batch: bf16 operands (as upstream's autocast), the batch zero-padded to one K step
+        Bp = _pad64(dy.shape[0])
+        a = torch.zeros((dy.shape[1], Bp), dtype=BF16, device=dy.device)
+        b = torch.zeros((_pad64(x.shape[1]) if x.shape[1] % 8 else x.shape[1], Bp), dtype=BF16, device=dy.device)
+        a[:, :dy.shape[0]] = dy.t()
+        b[:x.shape[1], :x.shape[0]] = x.t()
+        dw = _gemm_nt(a, b)[:, :x.shape[1]]
         return dx, dw, dy.sum(0)
 
     def bw():
@@ -532,13 +561,13 @@ def _conv_in(T: Tape, nt: _Net, x: torch.Tensor, B: int, w, b, conv: nn.Conv2d, 
             res.accumulate(dy)
         if nt.trainable:
             M = dy.shape[0]
-            Mp = _pad64(M)
+            Mp, nb = _plan_wgrad(M, ldo, 64)
             Nsrc, Cin, H, W = x.shape
             dyT = _transpose_pad(dy, M, ldo, Mp)
             xc = torch.empty((64, Mp), dtype=BF16, device=dy.device)
             _l.check(_l.load().ccnet_im2col_t_nchw_f32(x.data_ptr(), Nsrc, B, Cin, H, W, 1, xc.data_ptr(), Mp, 64, _stream()),
                      "im2col_t_nchw")
-            dw = _gemm_nt(dyT, xc).float()[:cout, :9 * Cin]  # rows k = tap * Cin + ci
+            dw = _gemm_nt(dyT, xc, nb=nb)[:cout, :9 * Cin]  # rows k = tap * Cin + ci
             T.add_grad(conv.weight, dw.view(cout, 3, 3, Cin).permute(0, 3, 1, 2))
             T.add_grad(conv.bias, _colsum(dy, 1)[0][:cout])
 
