@@ -402,6 +402,158 @@ bool launch_gn_onepass(const GnArgs& a, hipStream_t st) {
     return true;
 }
 
+// One-pass GroupNorm where a group is not a whole number of 16-byte vectors (10, 20, 30 channels per group: the 64x64 and
+// 32x32 levels of the 320 / 640 / 960-channel tensors): a block takes GQ adjacent groups whose channels together are whole
+// vectors (GQ * cpg % 8 == 0) and keeps that slice of the image (HW pixels x vpp vectors) in registers.  A thread always holds
+// the same vector column, whose 8 channels fall into at most two groups (cpg >= 8): it accumulates one partial per group,
+// the block reduces them in a fixed order (wave g sums group g's partials), two-pass mean / centred M2 as the other paths.
+// One read + one write of the tensor instead of the two reads + one write (and two launches) of the stats + apply pair.
+template <int MAXV>
+__global__ __launch_bounds__(1024) void gn_onepass_multi_kernel(const GnArgs a, int vpp, int GQ) {
+    __shared__ float s_part[1024][2];
+    __shared__ float s_grp[16];
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int bpi = a.groups / GQ;  // blocks per image
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    int n, gq;
+    if ((gridDim.x & 7) == 0 && (a.N & 7) == 0) { n = (j / bpi) * 8 + xcd; gq = j % bpi; }
+    else { n = blockIdx.x / bpi; gq = blockIdx.x % bpi; }
+    const int c0 = gq * GQ * a.cpg;  // first channel of this block's slice (a multiple of 8; the slice lies in one source)
+    const __bf16* src; int ld;
+    if (c0 < a.C1) { src = a.x1 + (long long)n * a.HW * a.ldx1 + c0; ld = a.ldx1; }
+    else { src = a.x2 + (long long)n * a.HW * a.ldx2 + (c0 - a.C1); ld = a.ldx2; }
+    const int nvec = a.HW * vpp;
+    const int jv = tid % vpp, p0 = tid / vpp, pstep = T / vpp;
+    // the vector's channels 8 jv .. 8 jv + 7 of the slice: the first `split` belong to local group gA, the rest to gA + 1
+    const int gA = (8 * jv) / a.cpg;
+    const int split = min(8, (gA + 1) * a.cpg - 8 * jv);
+    // one address register for all MAXV loads: per-thread byte offset in a VGPR, the per-vector stride in an SGPR (the slice
+    // itself fills the register file; 64-bit addresses per vector would not fit beside it)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(((long long)a.HW - 1) * ld * 2 + vpp * 16), 0x00020000);
+    const unsigned voff = (unsigned)(p0 * ld + jv * 8) * 2u;
+    const unsigned kstride = (unsigned)(pstep * ld) * 2u;
+    u32x4 v[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)  // (vectors beyond the slice fall outside the descriptor and read as zeros)
+        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(tid + k * T < nvec ? voff : 0x80000000u),
+                                                                               (int)(k * kstride), 0));
+    // fixed-order block reduction of the per-thread (group gA, group gA + 1) partials: wave g < GQ sums group g
+    auto group_sums = [&](float pa, float pb) {
+        __syncthreads();
+        s_part[tid][0] = pa; s_part[tid][1] = pb;
+        __syncthreads();
+        if (wave < GQ) {
+            float t = 0.f;
+            for (int u = lane; u < T; u += 64) {
+                const int ga = (8 * (u % vpp)) / a.cpg;
+                t += ga == wave ? s_part[u][0] : (ga + 1 == wave ? s_part[u][1] : 0.f);
+            }
+            t = wave_sum(t);
+            if (lane == 0) s_grp[wave] = t;
+        }
+        __syncthreads();
+    };
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        float f[8];
+        unpack8(v[k], f);  // (vectors beyond nvec are zeros)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sa += e < split ? f[e] : 0.f; sb += e < split ? 0.f : f[e]; }
+        __builtin_amdgcn_sched_barrier(0);  // one vector unpacked at a time
+    }
+    group_sums(sa, sb);
+    // (the packed slice is made opaque between the passes: hipcc otherwise keeps every vector's eight unpacked floats alive
+    // from one pass to the next, 176 registers instead of 88, and spills)
+    auto opaque = [&]() {
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) asm volatile("" : "+v"(v[k]));
+    };
+    opaque();
+    const float cnt = (float)a.HW * (float)a.cpg;
+    const float meanA = s_grp[gA] / cnt, meanB = gA + 1 < GQ ? s_grp[gA + 1] / cnt : 0.f;
+    sa = 0.f; sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        if (tid + k * T < nvec) {
+            float f[8];
+            unpack8(v[k], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = f[e] - (e < split ? meanA : meanB);
+                sa += e < split ? d * d : 0.f;
+                sb += e < split ? 0.f : d * d;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    group_sums(sa, sb);
+    opaque();
+    const float rstdA = rsqrtf(s_grp[gA] / cnt + a.eps), rstdB = gA + 1 < GQ ? rsqrtf(s_grp[gA + 1] / cnt + a.eps) : 0.f;
+    // per-channel scale / shift of the slice go through LDS (the registers hold the slice itself): threads of pixel lane 0
+    // write their vector column's 8 channels, every thread re-reads its column's two float4 pairs per vector (broadcast reads)
+    __shared__ __attribute__((aligned(16))) float s_ga[128], s_be[128];
+    if (p0 == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + jv * 8 + e;
+            const float g_ = a.gamma[c] * (e < split ? rstdA : rstdB);
+            s_ga[jv * 8 + e] = g_;
+            s_be[jv * 8 + e] = a.beta[c] - (e < split ? meanA : meanB) * g_;
+        }
+    }
+    __syncthreads();
+    __bf16* dst = a.out + (long long)n * a.HW * a.ldo + c0;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (unsigned)(((long long)a.HW - 1) * a.ldo * 2 + vpp * 16), 0x00020000);
+    const unsigned doff = (unsigned)(p0 * a.ldo + jv * 8) * 2u;
+    const unsigned dstride = (unsigned)(pstep * a.ldo) * 2u;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        {
+            float f[8];
+            unpack8(v[k], f);
+            const f32x4 g0 = *(const f32x4*)(s_ga + jv * 8), g1 = *(const f32x4*)(s_ga + jv * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(s_be + jv * 8), b1 = *(const f32x4*)(s_be + jv * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[e] = fmaf(f[e], g0[e], b0[e]);
+                f[4 + e] = fmaf(f[4 + e], g1[e], b1[e]);
+            }
+            if (a.silu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+            }
+            // (a vector beyond the slice is stored outside the descriptor, i.e. dropped)
+            __builtin_amdgcn_raw_buffer_store_b128(pack8(f), rd, (int)(tid + k * T < nvec ? doff : 0x80000000u), (int)(k * dstride), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one vector at a time: the slice fills the register file
+    }
+}
+
+template <int MAXV>
+bool launch_gn_onepass_multi(const GnArgs& a, hipStream_t st) {
+    // fewest groups per block whose channels are whole vectors; the slice must lie in one source and fit the registers
+    int GQ = 1;
+    while (GQ <= 16 && ((GQ * a.cpg) % 8 || (a.groups % GQ))) ++GQ;
+    if (GQ > 16 || a.cpg < 8 || GQ * a.cpg > 128) return false;
+    if (a.C2 > 0 && (a.C1 % (GQ * a.cpg))) return false;
+    const int vpp = GQ * a.cpg / 8;
+    int unit = vpp;
+    while (unit % 64) unit += vpp;
+    if (unit > 1024) return false;
+    const long long nvec = (long long)a.HW * vpp;
+    int T = unit;
+    while (T + unit <= 1024 && (long long)T * MAXV < nvec) T += unit;
+    if ((long long)T * MAXV < nvec) return false;
+    // measured (tools/ab_gn.sh, 32 images): 67 -> 50 us at 320 channels / 64x64 (256 blocks = one round of the chip), but
+    // 92 -> 111 us at 640 channels (512 blocks of 960 threads = two rounds, one block per CU): only when the blocks fill
+    // most of ONE round (16 waves of <= 128 registers per CU); the stats + apply pair spreads any size over >= 1024 blocks
+    const long long nblocks = (long long)a.N * (a.groups / GQ), slots = 256LL * (1024 / T);
+    if (nblocks > slots || nblocks * 4 < slots * 3) return false;
+    hipLaunchKernelGGL((gn_onepass_multi_kernel<MAXV>), dim3(a.N * (a.groups / GQ)), dim3(T), 0, st, a, vpp, GQ);
+    return true;
+}
+
 int g_gn_onepass = 2;  // tuning (ccnet_set_option key 6): 0 = always the two-kernel path, 1 / 2 / 3 = narrowest vector 16 / 8 / 4 B
 
 extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void* x2, int ldx2, int C2, int N,
@@ -428,6 +580,7 @@ extern "C" int ccnet_groupnorm_bf16(const void* x1, int ldx1, int C1, const void
         else if ((a.cpg % 4) == 0 && g_gn_onepass >= 2 && (long long)HW * a.cpg <= 65536)  // (measured: slower beyond)
             done = launch_gn_onepass<2, 22>(a, st);
         else if ((a.cpg % 2) == 0 && g_gn_onepass >= 3) done = launch_gn_onepass<1, 32>(a, st);
+        if (!done && (a.cpg % 8) != 0 && g_gn_onepass >= 2 && g_gn_onepass != 4) done = launch_gn_onepass_multi<22>(a, st);
         if (done) {
             CCNET_LAUNCH_CHECK();
             return CCNET_OK;

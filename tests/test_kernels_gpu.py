@@ -171,7 +171,11 @@ def test_gemm_batched(cuda):
 GN_CASES = [(2, 16, 16, 320, 0), (2, 8, 8, 1280, 1280), (1, 7, 7, 256, 0), (2, 32, 32, 128, 0), (3, 4, 4, 640, 320),
             (2, 64, 64, 320, 0),
             # one-pass kernel (channels per group % 8 == 0): XCD-grouped images, two sources, several vectors per thread
-            (8, 16, 16, 1280, 0), (16, 32, 32, 640, 640), (2, 16, 16, 2560, 0), (9, 8, 8, 1280, 0), (8, 32, 32, 1280, 640)]
+            (8, 16, 16, 1280, 0), (16, 32, 32, 640, 640), (2, 16, 16, 2560, 0), (9, 8, 8, 1280, 0), (8, 32, 32, 1280, 640),
+            # multi-group one-pass kernel (10 / 20 / 30 channels per group: a block takes 4 / 2 / 4 groups): the 64x64 and 32x32
+            # levels of 320 / 640-channel tensors, two sources whose boundary is a slice boundary, a ragged image count
+            (8, 64, 64, 320, 0), (3, 64, 64, 640, 0), (8, 32, 32, 320, 0), (2, 64, 64, 320, 320), (5, 16, 16, 960, 0),
+            (2, 24, 24, 320, 0)]
 
 
 @pytest.mark.parametrize("case", GN_CASES)
