@@ -103,6 +103,12 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
     // tr16 read addressing: 16-lane group g covers d columns 16g..16g+15 of the 32-wide d block; lane 4q+p of
     // the group supplies row q, columns 4p..4p+3.
     const int g16 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    int vlane[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int chunk = d * 4 + g16 * 2 + (tp >> 1);
+        vlane[d] = (4 * hh + tq) * 128 + ((chunk ^ (((tq >> 1) & 1) << 2)) << 4) + (tp & 1) * 8;
+    }
 
     const int ntiles = (a.Skv + KV_TILE - 1) / KV_TILE;
     issue_loads(0);
@@ -175,19 +181,18 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
             }
         l_run += rs;
 
-        // O^T[d][q] += V^T[d][key] * P^T[key][q]
+        // O^T[d][q] += V^T[d][key] * P^T[key][q].  A lane's transposed-read address = stage base + a lane constant per d
+        // block (row 4 hh + tq, swizzled chunk: the swizzle bit is bit 1 of tq, which the block offsets never touch) + the
+        // block's compile-time offset (kbk, sI, second four keys), so the sixteen reads carry immediate offsets only.
+        const char* vd[2] = {vb + vlane[0], vb + vlane[1]};
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int kbk = 0; kbk < NB; ++kbk)
 #pragma unroll
                 for (int sI = 0; sI < 2; ++sI) {
-                    const int key0 = kbk * 32 + 16 * sI + 4 * hh;  // first 4 keys; second 4 are +8
-                    const int chunk = (d * 32 + g16 * 16 + tp * 4) >> 3;       // 16-B chunk of the d column
-                    const int within = ((d * 32 + g16 * 16 + tp * 4) & 7) * 2;  // byte offset inside chunk
-                    const int r0 = key0 + tq, r1 = key0 + 8 + tq;
-                    const s16x4 lo = ds_read_tr16(vb + r0 * 128 + ((chunk ^ (((r0 >> 1) & 1) << 2)) << 4) + within);
-                    const s16x4 hi = ds_read_tr16(vb + r1 * 128 + ((chunk ^ (((r1 >> 1) & 1) << 2)) << 4) + within);
+                    const s16x4 lo = ds_read_tr16(vd[d] + kbk * 4096 + sI * 2048);
+                    const s16x4 hi = ds_read_tr16(vd[d] + kbk * 4096 + sI * 2048 + 1024);
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
                     const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[kbk][sI], o[d],
