@@ -229,6 +229,240 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
     }
 }
 
+// ------------------------------------------------------------------ long-key instance: 64 queries per wave
+// The same arithmetic as attn_d64_kernel for the self-attention shapes (Sq % 64 == 0, Skv % 64 == 0, no mask), arranged so
+// that a wave's LDS traffic per MFMA halves and nothing on the tile's critical path waits on LDS round trips:
+//   * a wave owns TWO 32-query blocks (A: q0 + l31, B: q0 + 32 + l31) at 2 waves per SIMD (256 registers): every K
+//     fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16 pair) feeds two MFMAs, and the two blocks'
+//     softmax chains are independent, so one block's VALU work sits beside the other block's MFMAs;
+//   * K / V tiles arrive by LDS-DMA (buffer_load ... lds, four 1-KiB pieces per wave and tile: no staging registers, no
+//     ds_write, no address arithmetic in the loop) into a 3-stage ring, issued two tiles ahead; one counted
+//     s_waitcnt vmcnt(4) + raw s_barrier per tile;
+//   * the lane^32 exchange of the row maximum / row sum is v_permlane32_swap (VALU) instead of ds_bpermute;
+//   * O leaves as 16-byte stores (permlane32 swap of the packed quads: a lane then holds 8 consecutive channels).
+__device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff,
+                                             (int)soff, 0, 0);
+}
+__device__ __forceinline__ float other_half_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ unsigned lds_off(const char* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+// two transposed 8-byte LDS reads (rows r and r + 8 of a V tile) = one bf16x8 A-operand fragment; the caller waits
+template <int OFF>
+__device__ __forceinline__ u32x4 tr_read_pair(unsigned addr) {
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 1024));
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+__global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnArgs a) {
+    constexpr int NSTG = 3, STG = 2 * TILE_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[NSTG * STG];  // per stage: K tile, V tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const bool wok = q0 < a.Sq;  // wave-uniform (Sq % 64 == 0); a wave beyond Sq still stages tiles and meets the barriers
+
+    // Q^T fragments (B operand) of the two query blocks
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const int qrow = wok ? q0 + 32 * X + l31 : 0;
+        const __bf16* qp = a.Q + ((long long)b * a.Sq + qrow) * a.ldq + h * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[X][ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ks * 16));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.K + (long long)b * a.Skv * a.ldk + h * 64), 0, a.k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.V + (long long)b * a.Skv * a.ldv + h * 64), 0, a.v_bytes, 0x00020000);
+    // DMA pieces: a tile is 8 K pieces + 8 V pieces of 8 rows x 128 B; wave w brings pieces 2w, 2w + 1 of each.  Lane l of a
+    // piece lands at chunk position l & 7 of row l >> 3 and fetches the chunk that the swizzled read expects there.
+    unsigned kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wave + i) * 8 + (lane >> 3), c = lane & 7;
+        kvo[i] = (unsigned)(r * a.ldk + ((c ^ ((r >> 1) & 7)) << 3)) * 2u;
+        vvo[i] = (unsigned)(r * a.ldv + ((c ^ (((r >> 1) & 1) << 2)) << 3)) * 2u;
+    }
+    const unsigned ktile_b = (unsigned)(KV_TILE * a.ldk) * 2u, vtile_b = (unsigned)(KV_TILE * a.ldv) * 2u;
+    auto issue_tile = [&](int t, int s) {
+        char* kb = smem + s * STG + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) attn_dma16(rk, kb + i * 1024, kvo[i], (unsigned)t * ktile_b);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) attn_dma16(rv, kb + TILE_BYTES + i * 1024, vvo[i], (unsigned)t * vtile_b);
+    };
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[X][d][e] = 0.f;
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+
+    const int kswz = (l31 >> 1) & 7;
+    const int g16 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    int vlane[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int chunk = d * 4 + g16 * 2 + (tp >> 1);
+        vlane[d] = (4 * hh + tq) * 128 + ((chunk ^ (((tq >> 1) & 1) << 2)) << 4) + (tp & 1) * 8;
+    }
+    int kread[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kread[ks] = l31 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+
+    const int ntiles = a.Skv / KV_TILE;
+    issue_tile(0, 0);
+    if (ntiles > 1) {
+        issue_tile(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int s = 0, sn = 2;
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 2 < ntiles;
+        if (more) issue_tile(t + 2, sn);
+        const char* kb = smem + s * STG;
+        const char* vb = kb + TILE_BYTES;
+
+        // S^T of both query blocks: a K fragment feeds two MFMAs
+        f32x16 sc[2][2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            bf16x8 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(kb + kbk * 4096 + kread[ks]);
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sc[X][kbk][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    sc[X][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[X][ks], sc[X][kbk], 0, 0, 0);
+            }
+        }
+        // V^T fragments of the whole tile, read by inline asm: hipcc puts an s_waitcnt vmcnt(0) in front of the
+        // ds_read_tr16_b64 builtin whenever LDS-DMAs are in flight (it cannot tell their target from the read's), which
+        // would drain the two-tile prefetch every tile.  Issued here, behind the S MFMAs, and waited for (explicit
+        // lgkmcnt) only in front of the P.V MFMAs, a softmax later.
+        u32x4 vfr[2][2][2];
+        const unsigned va0 = lds_off(vb) + (unsigned)vlane[0], va1 = lds_off(vb) + (unsigned)vlane[1];
+#define CCNET_VFRAG(kbk, sI)                                                          \
+        vfr[kbk][sI][0] = tr_read_pair<(kbk) * 4096 + (sI) * 2048>(va0);              \
+        vfr[kbk][sI][1] = tr_read_pair<(kbk) * 4096 + (sI) * 2048>(va1);
+        CCNET_VFRAG(0, 0) CCNET_VFRAG(0, 1) CCNET_VFRAG(1, 0) CCNET_VFRAG(1, 1)
+#undef CCNET_VFRAG
+        // online softmax per query block (deferred rescale, threshold 2^6 as in attn_d64_kernel)
+        float mx[2];
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m = fmaxf(m, sc[X][kbk][e]);
+            mx[X] = other_half_max(m) * a.scale_log2e;
+        }
+        constexpr float THR = 6.0f;
+        if (!__all(mx[0] - m_run[0] <= THR && mx[1] - m_run[1] <= THR)) {
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                const float m_new = fmaxf(m_run[X], mx[X]);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[X] - m_new);
+                m_run[X] = m_new;
+                l_run[X] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[X][d][e] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            bf16x8 pf[2][2];
+            float rs[4];
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    float p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        p[j] = __builtin_amdgcn_exp2f(fmaf(sc[X][kbk][8 * sI + j], a.scale_log2e, -m_run[X]));
+                    rs[2 * kbk + sI] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                    pf[kbk][sI] = __builtin_bit_cast(bf16x8, pack8(p));
+                }
+            l_run[X] += (rs[0] + rs[1]) + (rs[2] + rs[3]);
+            // O^T += V^T . P^T.  The wait names the fragments, so every MFMA below depends on it.
+            if (X == 0)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(vfr[0][0][0]), "+v"(vfr[0][0][1]), "+v"(vfr[0][1][0]), "+v"(vfr[0][1][1]),
+                               "+v"(vfr[1][0][0]), "+v"(vfr[1][0][1]), "+v"(vfr[1][1][0]), "+v"(vfr[1][1][1]));
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+                        o[X][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr[kbk][sI][d]),
+                                                                         pf[kbk][sI], o[X][d], 0, 0, 0);
+        }
+        // tile t + 1 has landed (mine: counted wait; everyone's: barrier); tile t + 2 stays in flight
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        s = s + 1 == NSTG ? 0 : s + 1;
+        sn = sn + 1 == NSTG ? 0 : sn + 1;
+    }
+
+    if (!wok) return;
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[X]), __float_as_uint(l_run[X]), false, false);
+        const float l_tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + 32 * X + l31;
+        if (a.lse && hh == 0) a.lse[((long long)b * a.H + h) * a.Sq + qrow] = m_run[X] + __builtin_amdgcn_logf(l_tot);
+        __bf16* op = a.O + ((long long)b * a.Sq + qrow) * a.ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                // quads 2 qp (channels 16 qp + 4 hh ..) and 2 qp + 1 (16 qp + 8 + 4 hh ..): after the swap the lower
+                // lane half holds channels 16 qp .. + 7 of its query, the upper half channels 16 qp + 8 .. + 15
+                u32x4 v;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const unsigned e0 = pack_bf16x2(o[X][d][8 * qp + 2 * w] * inv, o[X][d][8 * qp + 2 * w + 1] * inv);
+                    const unsigned e1 = pack_bf16x2(o[X][d][8 * qp + 4 + 2 * w] * inv, o[X][d][8 * qp + 4 + 2 * w + 1] * inv);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(e0, e1, false, false);
+                    v[w] = sw[0];
+                    v[2 + w] = sw[1];
+                }
+                *(u32x4*)(op + d * 32 + 16 * qp + 8 * hh) = v;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ attention backward (training), head dim 64
 // Two passes, each a re-arrangement of the forward kernel, both recomputing P from Q, K and the forward's LSE (no N x N
 // tensor in memory, no atomics: every gradient element is written by exactly one lane, so the step is bit-reproducible):
@@ -582,6 +816,8 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const __bf16* x, int
 
 }  // namespace
 
+int g_attn_mode = 0;  // tuning (ccnet_set_option key 7): 0 = by shape, 1 = always attn_d64_kernel, 2 = attn_d64_w64_kernel wherever it applies
+
 namespace {
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H,
                      int Sq, int Skv, float scale, bool causal, void* stream, float* lse = nullptr) {
@@ -598,8 +834,13 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     a.scale_log2e = scale * 1.4426950408889634f;
     a.k_bytes = (unsigned)kb; a.v_bytes = (unsigned)vb;
     a.lse = lse;
+    // 64 queries per wave: the long-key self-attention shapes (whole 64-key tiles, no mask)
+    const bool w64_ok = !causal && (Sq % 64) == 0 && (Skv % 64) == 0 && (ldo % 8) == 0;
+    const bool w64 = w64_ok && (g_attn_mode == 2 || (g_attn_mode == 0 && Skv >= 256));
     if (causal)
         hipLaunchKernelGGL(attn_d64_kernel<true>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
+    else if (w64)
+        hipLaunchKernelGGL(attn_d64_w64_kernel, dim3((Sq + 255) / 256, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(attn_d64_kernel<false>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     CCNET_LAUNCH_CHECK();

@@ -851,6 +851,7 @@ int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, in
 }  // namespace
 
 extern int g_gn_onepass;  // norm.hip
+extern int g_attn_mode;   // attention.hip
 
 extern "C" int ccnet_set_option(int key, int value) {
     if (key == 0) { g_force_cfg = value; return CCNET_OK; }  // force conv tile configuration (-1 = heuristic)
@@ -859,6 +860,7 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 3) { g_force_splitk = value; return CCNET_OK; }
     if (key == 4) { g_persist = value; return CCNET_OK; }
     if (key == 6) { g_gn_onepass = value; return CCNET_OK; }
+    if (key == 7) { g_attn_mode = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
