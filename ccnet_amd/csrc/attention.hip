@@ -240,6 +240,13 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
 //     s_waitcnt vmcnt(4) + raw s_barrier per tile;
 //   * the lane^32 exchange of the row maximum / row sum is v_permlane32_swap (VALU) instead of ds_bpermute;
 //   * O leaves as 16-byte stores (permlane32 swap of the packed quads: a lane then holds 8 consecutive channels).
+// At head dim 64 the tile is bound by vector issue, not by the matrix pipe: per wave and 64-key tile 64 exp + 64 fma + 64 add
+// + 32 max3 + 32 cvt ~ 1500 issue cycles against 1024 cycles of MFMA (SQ counters: VALU active 0.40 of wave cycles at two
+// waves per SIMD, matrix pipe busy 0.51), so the two waves of a SIMD overlap each other's phases and that is most of what
+// there is to get.  Measured against this form and dropped (profiles/r02_attn_variants.txt): an 8-wave block whose two groups
+// are held half a tile apart by barriers (one wave of a SIMD in its MFMAs while the other is in its softmax: -12 %), and a
+// software pipeline over 32-key blocks inside the wave (S(j+1) and P.V(j-1) beside the softmax of block j, all LDS reads by
+// inline asm with counted waits: -3 %: twice the maxima / branches per tile).
 __device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff,
                                              (int)soff, 0, 0);

@@ -336,18 +336,22 @@ def test_attention_d64(cuda, case):
     _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attention {case}")
 
 
-@pytest.mark.parametrize("case", [(1, 2, 128, 64), (2, 1, 192, 128), (1, 3, 320, 192), (2, 2, 64, 320), (1, 1, 576, 1024)])
-def test_attention_d64_long_key_instance(cuda, case):
+@pytest.mark.parametrize("case", [(1, 2, 128, 64), (2, 1, 192, 128), (1, 3, 320, 192), (2, 2, 64, 320), (1, 1, 576, 1024),
+                                  (1, 2, 1024, 256)])
+def test_attention_d64_long_key_instance(cuda, case, mode=2):
     """The 64-queries-per-wave instance (LDS-DMA ring of three K/V tiles) forced onto shapes that exercise its edges: one,
-    two and three key tiles (ring start-up / drain), query counts that leave waves of the last block without rows."""
+    two and three key tiles (ring start-up / drain), query counts that leave waves of the last block without rows; a late
+    dominant key (rescale branch)."""
     ops = _ops()
     from ccnet_amd import lib as L
     B, H, Sq, Skv = case
     g = torch.Generator().manual_seed(53)
-    qkv = torch.randn(B * Sq, 3 * H * 64, generator=g).to(torch.bfloat16).to(cuda)
-    kv = (torch.randn(B * Skv, 2 * H * 64, generator=g) * 1.5).to(torch.bfloat16).to(cuda)
+    qkv = torch.randn(B * Sq, 3 * H * 64, generator=g)
+    kv = torch.randn(B * Skv, 2 * H * 64, generator=g) * 1.5
+    kv[Skv - 5, :64] = qkv[3, H * 64: H * 64 + 64] * 4.0  # spike for query 3 of head 0 in the last key tile
+    qkv, kv = qkv.to(torch.bfloat16).to(cuda), kv.to(torch.bfloat16).to(cuda)
     q, k, v = qkv[:, H * 64: 2 * H * 64], kv[:, : H * 64], kv[:, H * 64:]
-    assert L.load().ccnet_set_option(7, 2) == 0
+    assert L.load().ccnet_set_option(7, mode) == 0
     try:
         o = ops.attention_d64(q, k, v, B, H, Sq, Skv, 0.125)
         assert L.load().ccnet_set_option(7, 1) == 0
@@ -359,8 +363,8 @@ def test_attention_d64_long_key_instance(cuda, case):
     vf = v.float().reshape(B, Skv, H, 64).permute(0, 2, 1, 3)
     p = torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, dim=-1)
     ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * Sq, H * 64)
-    _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attention (64 queries per wave) {case}")
-    _close(o.float(), o_ref_kernel.float(), atol=1.5e-2, rtol=2.0 ** -6, what=f"attention: the two instances agree {case}")
+    _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attention (mode {mode}) {case}")
+    _close(o.float(), o_ref_kernel.float(), atol=1.5e-2, rtol=2.0 ** -6, what=f"attention: instances agree (mode {mode}) {case}")
 
 
 def test_attention_rescale_branch(cuda):
