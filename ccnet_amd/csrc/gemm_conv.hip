@@ -767,6 +767,12 @@ const TileCfg kCfgs[] = {
      launch<4, 2, 1, 5, false, 2, 64, false, false, false, true>, 160},          // 29: 8 waves of 32 x 160, 114 KB
     {128, 320, launch<4, 2, 1, 5, false, 2, 64, false, true, true>, nullptr, nullptr,
      launch<4, 2, 1, 5, false, 2, 64, false, true, true, true>, 160},            // 30: 29, persistent, residual prefetch
+#ifdef CCNET_EXP_TILES
+    // diagnostic build only (tools/build_variant.sh exp "-DCCNET_EXP_TILES" gemm_conv): one wave per SIMD, 128 x 160 /
+    // 128 x 128 wave tiles (0.45 / 0.5 LDS fragment reads per MFMA instead of 0.7 / 0.75); hipcc spills in their epilogues
+    {256, 320, launch<2, 2, 4, 5, false, 2, 64>, nullptr, nullptr},             // 31
+    {256, 256, launch<2, 2, 4, 4, false, 2, 64>, nullptr, nullptr},             // 32
+#endif
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // 256 pixels x 32 couts, 4 waves, two blocks per CU: the output convolutions (Cout <= 8); raw-accumulator epilogue
