@@ -268,6 +268,11 @@ __device__ __forceinline__ u32x4 tr_read_pair(unsigned addr) {
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// PRE: Q already carries scale * log2(e) (folded into the query projection's weights when they are packed), and the scores
+// leave the matrix core already relative to the row's reference maximum: one more MFMA per score block multiplies a column of
+// ones on the K side with a row of -m on the Q side (k slot 0 of an extra 16-deep step), with m kept bf16-representable so
+// that the product is exact.  The exponential's argument then needs no fma: 64 of the tile's ~315 vector instructions go.
+template <bool PRE>
 __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnArgs a) {
     constexpr int NSTG = 3, STG = 2 * TILE_BYTES;
     __shared__ __attribute__((aligned(1024))) char smem[NSTG * STG];  // per stage: K tile, V tile
@@ -318,7 +323,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnA
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[X][d][e] = 0.f;
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+    // (PRE: the reference starts at 0 and the first tile always takes the re-reference path)
+    float m_run[2] = {PRE ? 0.f : -1e30f, PRE ? 0.f : -1e30f}, l_run[2] = {0.f, 0.f};
+    // PRE: A fragment with 1.0 in k slot 0 of every key row, B fragments with -m of the lane's query in k slot 0
+    const u32x4 ones = {hh == 0 ? 0x3f80u : 0u, 0u, 0u, 0u};
+    u32x4 qm[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
 
     const int kswz = (l31 >> 1) & 7;
     const int g16 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -361,6 +370,9 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnA
             for (int X = 0; X < 2; ++X) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sc[X][kbk][e] = 0.f;
+                if constexpr (PRE)
+                    sc[X][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones),
+                                                                        __builtin_bit_cast(bf16x8, qm[X]), sc[X][kbk], 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     sc[X][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[X][ks], sc[X][kbk], 0, 0, 0);
@@ -386,10 +398,34 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnA
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) m = fmaxf(m, sc[X][kbk][e]);
-            mx[X] = other_half_max(m) * a.scale_log2e;
+            mx[X] = PRE ? other_half_max(m) : other_half_max(m) * a.scale_log2e;
         }
         constexpr float THR = 6.0f;
-        if (!__all(mx[0] - m_run[0] <= THR && mx[1] - m_run[1] <= THR)) {
+        if constexpr (PRE) {
+            // scores are relative to m_run already; the first tile sets the reference (in either direction), later tiles
+            // only raise it.  The new reference is rounded to bf16 (the -m fragment must hold it exactly).
+            if (t == 0 || !__all(mx[0] <= THR && mx[1] <= THR)) {
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    const float want = m_run[X] + (t == 0 ? mx[X] : fmaxf(mx[X], 0.f));
+                    const unsigned short mb = f32_to_bf16_bits(want);
+                    const float m_new = bf16_bits_to_f32(mb);
+                    const float delta = m_new - m_run[X];
+                    const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                    m_run[X] = m_new;
+                    qm[X][0] = hh == 0 ? (unsigned)(mb ^ 0x8000u) : 0u;
+                    l_run[X] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[X][d][e] *= alpha;
+#pragma unroll
+                    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) sc[X][kbk][e] -= delta;
+                }
+            }
+        } else if (!__all(mx[0] - m_run[0] <= THR && mx[1] - m_run[1] <= THR)) {
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
                 const float m_new = fmaxf(m_run[X], mx[X]);
@@ -413,7 +449,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnA
                     float p[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        p[j] = __builtin_amdgcn_exp2f(fmaf(sc[X][kbk][8 * sI + j], a.scale_log2e, -m_run[X]));
+                        p[j] = PRE ? __builtin_amdgcn_exp2f(sc[X][kbk][8 * sI + j])
+                                   : __builtin_amdgcn_exp2f(fmaf(sc[X][kbk][8 * sI + j], a.scale_log2e, -m_run[X]));
                     rs[2 * kbk + sI] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                     pf[kbk][sI] = __builtin_bit_cast(bf16x8, pack8(p));
                 }
@@ -827,7 +864,7 @@ int g_attn_mode = 0;  // tuning (ccnet_set_option key 7): 0 = by shape, 1 = alwa
 
 namespace {
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H,
-                     int Sq, int Skv, float scale, bool causal, void* stream, float* lse = nullptr) {
+                     int Sq, int Skv, float scale, bool causal, void* stream, float* lse = nullptr, bool prescaled = false) {
     if (!Q || !K || !V || !O) return CCNET_EINVAL;
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return CCNET_EINVAL;
     if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 4)) return CCNET_EINVAL;
@@ -838,7 +875,7 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     AttnArgs a{};
     a.Q = (const __bf16*)Q; a.K = (const __bf16*)K; a.V = (const __bf16*)V; a.O = (__bf16*)O;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv;
-    a.scale_log2e = scale * 1.4426950408889634f;
+    a.scale_log2e = prescaled ? 1.0f : scale * 1.4426950408889634f;
     a.k_bytes = (unsigned)kb; a.v_bytes = (unsigned)vb;
     a.lse = lse;
     // 64 queries per wave: the long-key self-attention shapes (whole 64-key tiles, no mask)
@@ -846,8 +883,10 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     const bool w64 = w64_ok && (g_attn_mode == 2 || (g_attn_mode == 0 && Skv >= 256));
     if (causal)
         hipLaunchKernelGGL(attn_d64_kernel<true>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
+    else if (w64 && prescaled)
+        hipLaunchKernelGGL(attn_d64_w64_kernel<true>, dim3((Sq + 255) / 256, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     else if (w64)
-        hipLaunchKernelGGL(attn_d64_w64_kernel, dim3((Sq + 255) / 256, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(attn_d64_w64_kernel<false>, dim3((Sq + 255) / 256, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(attn_d64_kernel<false>, dim3((Sq + 127) / 128, H, B), dim3(AT_THREADS), 0, (hipStream_t)stream, a);
     CCNET_LAUNCH_CHECK();
@@ -858,6 +897,11 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
 extern "C" int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                                         void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream) {
     return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, scale, false, stream);
+}
+
+extern "C" int ccnet_attention_d64_prescaled_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                                  void* O, int ldo, int B, int H, int Sq, int Skv, void* stream) {
+    return launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, 1.0f, false, stream, nullptr, true);
 }
 
 extern "C" int ccnet_attention_d64_lse_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,

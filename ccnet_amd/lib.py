@@ -27,6 +27,7 @@ EXPORTS = [
     "ccnet_im2col_t_bf16", "ccnet_im2col_t_nchw_f32", "ccnet_colsum_bf16", "ccnet_groupnorm_bwd_bf16",
     "ccnet_layernorm_bwd_bf16", "ccnet_softmax_bwd_rows_bf16", "ccnet_geglu_bwd_bf16", "ccnet_silu_bf16", "ccnet_axpby_bf16",
     "ccnet_resample_bwd_bf16", "ccnet_attention_d64_lse_bf16", "ccnet_attention_d64_bwd_bf16",
+    "ccnet_attention_d64_prescaled_bf16",
 ]
 
 
@@ -84,6 +85,7 @@ def load() -> C.CDLL:
     lib.ccnet_geglu_bf16.argtypes = [vp, i, i, i, vp, i, vp]
     lib.ccnet_attention_d64_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, vp]
     lib.ccnet_attention_d64_causal_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, f, vp]
+    lib.ccnet_attention_d64_prescaled_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
     lib.ccnet_embed_tokens_bf16.argtypes = [vp, i, i, i, vp, vp, i, vp, i, vp]
     lib.ccnet_gelu_bf16.argtypes = [vp, i, i, i, i, vp, i, vp]
     lib.ccnet_softmax_rows_bf16.argtypes = [vp, i, i, i, i, f, vp, i, vp]

@@ -37,6 +37,9 @@ BF16 = torch.bfloat16
 # without -- the write it saves is served from the Infinity Cache anyway and the GEMM's accumulator start gets heavier -- so
 # the separate LayerNorm kernel stays the default and the fold is an option (parity-tested either way).
 LN_FOLD = os.environ.get("CCNET_LN_FOLD", "0") == "1"
+# Head dim 64: softmax scale * log2(e) folded into the packed to_q weights (one bf16 rounding of the scaled fp32 weight), the
+# attention kernel then runs its prescaled instance (no multiply in front of the exponential).  CCNET_ATTN_PRESCALE=0: A/B.
+ATTN_PRESCALE = os.environ.get("CCNET_ATTN_PRESCALE", "1") == "1"
 
 
 def _tuple(v, n):
@@ -253,6 +256,7 @@ class _Trunk(nn.Module):
         def pattn(a: _Holder):
             b = a.transformer_blocks[0]
             inner = a.heads * a.head_ch
+            qscale = math.log2(math.e) / math.sqrt(a.head_ch)
             # LayerNorm folded into the linear layer that consumes it (ops.fold_layernorm; the GEMM kernel applies the row
             # statistics): norm1 -> to_q|to_k|to_v, norm2 -> attn2.to_q, norm3 -> ff.linear1 (then the GEGLU interleave)
             f_qkv = f_q2 = f_ff1 = None
@@ -270,6 +274,11 @@ class _Trunk(nn.Module):
                 "ln1": (f32(b.norm1.weight), f32(b.norm1.bias)), "ln2": (f32(b.norm2.weight), f32(b.norm2.bias)),
                 "ln3": (f32(b.norm3.weight), f32(b.norm3.bias)),
                 "qkv1": plin(torch.cat([b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight], 0)),
+                # head dim 64: the softmax scale (and the log2(e) of the kernel's exp2) folded into to_q before the one
+                # rounding to bf16, so the flash kernel's exponent needs no multiply (ccnet_attention_d64_prescaled_bf16)
+                "qkv1s": plin(torch.cat([b.attn1.to_q.weight.detach().float() * qscale, b.attn1.to_k.weight.detach().float(),
+                                         b.attn1.to_v.weight.detach().float()], 0)) if ATTN_PRESCALE and a.head_ch == 64 else None,
+                "q2s": plin(b.attn2.to_q.weight.detach().float() * qscale) if ATTN_PRESCALE and a.head_ch == 64 else None,
                 "o1": (plin(b.attn1.to_out[0].weight), f32(b.attn1.to_out[0].bias)),
                 "q2": plin(b.attn2.to_q.weight),
                 "kv2": plin(torch.cat([b.attn2.to_k.weight, b.attn2.to_v.weight], 0)),
@@ -421,9 +430,11 @@ class _Trunk(nn.Module):
         if hc % 64:
             raise CcnetError(f"attention head dim {hc}: the MI355X lowering needs num_head_channels % 64 == 0")
 
+        pre = (not LN_FOLD) and p["qkv1s"] is not None
+
         def attend(q, k, v, Skv):
             if hc == 64:  # flash kernel (SD-2.1 geometry)
-                return ops.attention_d64(q, k, v, B, heads, T, Skv, scale)
+                return ops.attention_d64(q, k, v, B, heads, T, Skv, scale, prescaled=pre)
             return ops.attention_generic(q, k, v, B, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
         h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.transformer_norm_eps, False)
         if LN_FOLD:
@@ -445,10 +456,10 @@ class _Trunk(nn.Module):
             gl = ops.linear(t, w, b, 8 * inner, inner, act=2, rowstat=stats_of(t, st), colsum=cs)
         else:
             t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
-            qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1"], None, 3 * inner, inner)
+            qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1s"] if pre else p["qkv1"], None, 3 * inner, inner)
             o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
             t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
-            q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2"], None, inner, inner)
+            q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
             o = attend(q, kv[:, :inner], kv[:, inner:], S)
             t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
             gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)

@@ -226,11 +226,17 @@ def geglu(x2d: torch.Tensor, Cc: int) -> torch.Tensor:
 
 
 def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
-                  scale: float) -> torch.Tensor:
-    """q [B*Sq, >=H*64] (views allowed), k/v [B*Skv, >=H*64] -> o [B*Sq, H*64]."""
+                  scale: float, prescaled: bool = False) -> torch.Tensor:
+    """q [B*Sq, >=H*64] (views allowed), k/v [B*Skv, >=H*64] -> o [B*Sq, H*64].  prescaled: q already carries
+    scale * log2(e) (ATTN_PRESCALE, folded into the query projection by the caller); `scale` is then ignored."""
     lib = _l.load()
     _need_cuda(q, k, v)
     o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
+    if prescaled:
+        _l.check(lib.ccnet_attention_d64_prescaled_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                                        v.stride(0), o.data_ptr(), o.stride(0), B, H, Sq, Skv, _stream()),
+                 "attention_d64_prescaled")
+        return o
     _l.check(lib.ccnet_attention_d64_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                           v.stride(0), o.data_ptr(), o.stride(0), B, H, Sq, Skv, scale, _stream()),
              "attention_d64")

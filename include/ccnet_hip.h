@@ -165,6 +165,12 @@ int ccnet_geglu_bf16(const void* x, int ldx, int rows, int C, void* out, int ldo
 int ccnet_attention_d64_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                              void* O, int ldo, int B, int H, int Sq, int Skv, float scale, void* stream);
 
+/* The same product for a Q that already carries scale * log2(e) (the caller folded it into the query projection's weights
+ * and bias, as ccnet_amd.nets does when it packs to_q: same reference call as above, CrossAttention._attention): the softmax is
+ * then exp2 of the raw scores, and the long-key instance takes the row maximum off inside the matrix core. */
+int ccnet_attention_d64_prescaled_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                       void* O, int ldo, int B, int H, int Sq, int Skv, void* stream);
+
 /* Causal self-attention (key j <= query i), same layout and kernel: the CLIP text tower's masked attention
  * (transformers CLIPTextModel, called at run_controlnet_inference.py:149,205 as text_encoder(input_ids)). */
 int ccnet_attention_d64_causal_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,

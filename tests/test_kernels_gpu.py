@@ -367,6 +367,31 @@ def test_attention_d64_long_key_instance(cuda, case, mode=2):
     _close(o.float(), o_ref_kernel.float(), atol=1.5e-2, rtol=2.0 ** -6, what=f"attention: instances agree (mode {mode}) {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 5, 256, 256), (1, 2, 128, 64), (1, 3, 320, 192), (1, 1, 576, 1024), (2, 2, 200, 77)])
+def test_attention_d64_prescaled(cuda, case):
+    """Q that already carries scale * log2(e): the long-key instance takes the row maximum off inside the matrix core (an extra
+    MFMA against -m kept bf16-exact), shorter / ragged shapes run the round-1 kernel with a unit scale.  Reference: softmax of
+    the same (bf16) scaled Q in the log2 domain.  A late dominant key and a first tile far below zero exercise both
+    directions of the reference maximum."""
+    ops = _ops()
+    B, H, Sq, Skv = case
+    g = torch.Generator().manual_seed(57)
+    c = math.log2(math.e) / 8.0
+    q = (torch.randn(B * Sq, H * 64, generator=g) * c)
+    k = torch.randn(B * Skv, H * 64, generator=g) * 1.5
+    v = torch.randn(B * Skv, H * 64, generator=g)
+    k[Skv - 5, :64] = q[3, :64] / c * 4.0            # spike for query 3 of head 0 in the last key tile
+    k[:64, :64] -= q[7, :64] / c * 3.0               # query 7: every score of the first tile far below zero
+    qb, kb, vb = (t.to(torch.bfloat16).to(cuda) for t in (q, k, v))
+    o = ops.attention_d64(qb, kb, vb, B, H, Sq, Skv, 0.0, prescaled=True)
+    qf = qb.float().reshape(B, Sq, H, 64).permute(0, 2, 1, 3)
+    kf = kb.float().reshape(B, Skv, H, 64).permute(0, 2, 1, 3)
+    vf = vb.float().reshape(B, Skv, H, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(qf @ kf.transpose(-1, -2) * math.log(2.0), dim=-1)   # exp2(s) / sum exp2(s)
+    ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * Sq, H * 64)
+    _close(o.float(), ref, atol=1.5e-2, rtol=2.0 ** -6, what=f"prescaled attention {case}")
+
+
 def test_attention_rescale_branch(cuda):
     """Online-softmax rescale: a key in a LATE tile dominates, so the running max jumps after O has mass."""
     ops = _ops()

