@@ -63,6 +63,9 @@ struct ConvArgs {
 #endif
 };
 
+#ifndef CCNET_DMA_FRONT
+#define CCNET_DMA_FRONT 2   // MFMA k-steps of a K-step that carry its DMA issues (tuning builds: -DCCNET_DMA_FRONT=n)
+#endif
 constexpr unsigned OOB = 0x80000000u;  // beyond any num_records we accept (< 2^31 bytes)
 
 __device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t r, char* lds_wave_base, unsigned voff) {
@@ -361,7 +364,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
             for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * RB + co);
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * RB + co);
-            if (more) issue_slice(sn, (NL * ks) / KS, (NL * (ks + 1)) / KS);
+            // The step's DMAs go out within its first two MFMA k-steps, not spread over all four: with two stages the wait
+            // that ends the step follows the last issue by the rest of the step only, and a quarter of the stage issued in
+            // the last k-step had ~600 cycles to land (measured: +3..7 % on every 64-deep layer, tools/bench_conv.py
+            // --cold, profiles/r02_dma_front.txt; all in the first k-step is neutral: the burst delays that k-step's MFMAs)
+            constexpr int KF = CCNET_DMA_FRONT < KS ? CCNET_DMA_FRONT : KS;
+            if (more && ks < KF) issue_slice(sn, (NL * ks) / KF, (NL * (ks + 1)) / KF);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
