@@ -63,9 +63,6 @@ struct ConvArgs {
 #endif
 };
 
-#ifndef CCNET_KROT
-#define CCNET_KROT 1        // 1: rotated K loop (see there); 0: the barrier at the end of the step (A/B builds)
-#endif
 #ifndef CCNET_DMA_FRONT
 #define CCNET_DMA_FRONT 2   // MFMA k-steps of a K-step that carry its DMA issues (tuning builds: -DCCNET_DMA_FRONT=n)
 #endif
@@ -354,59 +351,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     asm volatile("" ::: "memory");
     STAMP(2);
     int s = 0, sn = NS - 1;  // stage being read, stage being refilled
-#if CCNET_KROT
-    // Rotated K loop: the wait + barrier that hands over the next stage sits in front of the step's LAST MFMA k-step, whose
-    // fragments are in registers by then, and the next stage's first fragments are read right behind the barrier -- so the
-    // LDS round trip that opens a stage runs under the last k-step's MFMAs instead of with the matrix pipe drained.  Every
-    // read of the current stage is issued (and, lgkmcnt, returned) before that barrier, so the stage may be refilled by the
-    // DMAs the next step issues; those go out in the step's first k-steps (KF <= KS - 1) and have the rest of it to land.
-    constexpr int KF = CCNET_DMA_FRONT < KS - 1 ? CCNET_DMA_FRONT : KS - 1;
-    bf16x8 af[TI], bfr[TJ];
-    auto read_frags = [&](int stage, int ks, bf16x8* A, bf16x8* B) {
-        const char* xb = smem + stage * STAGE;
-        const char* wb = xb + BM * RB;
-        const int co = ((2 * ks + hh) ^ swz) << 4;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) A[i] = *(const bf16x8*)(wb + wrow_off + i * 32 * RB + co);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) B[j] = *(const bf16x8*)(xb + xrow_off + j * 32 * RB + co);
-    };
-    read_frags(0, 0, af, bfr);
-    for (int kt = 0; kt < KTl; ++kt) {
-        const bool more = kt + NS - 1 < KTl;
-        const int s1 = s + 1 == NS ? 0 : s + 1;
-        if (more && cc_n == 0) set_tap(tap_n);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 naf[TI], nbf[TJ];
-            if (ks == KS - 1) {
-                if (more) {
-                    advance();
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL * (NS - 2)) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (kt + 1 < KTl) read_frags(s1, 0, naf, nbf);
-            } else {
-                read_frags(s, ks + 1, naf, nbf);
-            }
-            if (more && ks < KF) issue_slice(sn, (NL * ks) / KF, (NL * (ks + 1)) / KF);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = naf[i];
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bfr[j] = nbf[j];
-        }
-        s = s1;
-        sn = sn + 1 == NS ? 0 : sn + 1;
-    }
-#else
     for (int kt = 0; kt < KTl; ++kt) {
         const bool more = kt + NS - 1 < KTl;
         const char* xb = smem + s * STAGE;
@@ -423,7 +367,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
             // The step's DMAs go out within its first two MFMA k-steps, not spread over all four: with two stages the wait
             // that ends the step follows the last issue by the rest of the step only, and a quarter of the stage issued in
             // the last k-step had ~600 cycles to land (measured: +3..7 % on every 64-deep layer, tools/bench_conv.py
-            // --cold, profiles/r02_dma_front.txt; all in the first k-step is neutral: the burst delays that k-step's MFMAs)
+            // --cold, profiles/r02_dma_front.txt; all in the first k-step is neutral: the burst delays that k-step's MFMAs).
+            // Also measured there and dropped: the loop rotated so that wait + barrier sit in front of the step's last
+            // k-step and the next stage's first fragments are read under its MFMAs (-9 % on the 256x320 tile, which has no
+            // registers for it, -1 % elsewhere: the DMAs then have two k-steps instead of the whole step to land).
             constexpr int KF = CCNET_DMA_FRONT < KS ? CCNET_DMA_FRONT : KS;
             if (more && ks < KF) issue_slice(sn, (NL * ks) / KF, (NL * (ks + 1)) / KF);
 #pragma unroll
@@ -444,7 +391,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
         sn = sn + 1 == NS ? 0 : sn + 1;
     }
 
-#endif
     STAMP(3);
     bool last = true;
     if constexpr (PERSIST) {
