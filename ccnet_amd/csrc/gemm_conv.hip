@@ -694,6 +694,137 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- 320 -> 320 pointwise layers of the 64x64 level
+// o-proj (+ residual), proj_in / proj_out (+ residual), attn2.to_q at 320 channels: K = 320 gives 160 FLOP per byte, far
+// below the machine balance, and in the tiled kernel a CU alternates between a K loop (HBM idle) and an epilogue (matrix
+// core idle): 2.8-3.0 TB/s of algorithmic traffic.  Here the WEIGHTS never move: a block is 10 waves, wave w keeps the A
+// fragments of couts 32 w .. 32 w + 31 for the whole K = 320 in 80 registers, and the block streams its share of the pixel
+// rows in chunks of 32 through a ring of four LDS stages (LDS-DMA, 20 KB per chunk, issued three chunks ahead).  Per chunk a
+// wave does 20 MFMAs (B fragments = the chunk's rows, shared by all ten waves), adds the residual rows it prefetched one
+// chunk earlier and stores 32 x 32 outputs -- loads, MFMAs and stores of neighbouring chunks overlap all the time, there is
+// no tile epilogue.  Results are bit-identical to the tiled kernel (same k order, accumulators start at the bias).
+constexpr int PW_C = 320, PW_WAVES = PW_C / 32, PW_ROWS = 32, PW_NSTG = 4, PW_ROWB = PW_C * 2, PW_CHUNKB = PW_ROWS * PW_ROWB;
+struct PwArgs {
+    const __bf16* x; const __bf16* w; const float* bias; const __bf16* res; __bf16* out;
+    int M, ldx, ldw, ldres, ldo, chunks, chunks_per_block;
+    unsigned x_bytes;
+};
+
+template <bool RES>
+__global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a) {
+    __shared__ __attribute__((aligned(1024))) char smem[PW_NSTG * PW_CHUNKB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int c_lo = blockIdx.x * a.chunks_per_block;
+    const int c_hi = min(c_lo + a.chunks_per_block, a.chunks);
+    if (c_lo >= c_hi) return;  // (whole block: no barrier is pending)
+
+    // the wave's weight fragments: lane holds W[32 wave + l31][16 ks + 8 hh .. + 7]
+    bf16x8 wf[PW_C / 16];
+    {
+        const __bf16* wp = a.w + (long long)(32 * wave + l31) * a.ldw + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < PW_C / 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wp + 16 * ks));
+    }
+    // accumulator start: bias of couts 32 wave + 8 q + 4 hh + e
+    f32x16 bq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = a.bias ? *(const f32x4*)(a.bias + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[4 * q + e] = t[e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    // DMA: a chunk is 20 pieces of 64 16-byte units (40 units per row); wave w brings pieces 2 w, 2 w + 1.  The unit that
+    // lands at position p of row r is unit (p & ~7) | ((p ^ (r >> 1)) & 7) of that row: conflict-free ds_read_b128 below.
+    unsigned dvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = (2 * wave + i) * 64 + lane, r = u / 40, pp = u - r * 40;
+        const int unit = (pp & ~7) | ((pp ^ (r >> 1)) & 7);
+        dvo[i] = (unsigned)(r * a.ldx + unit * 8) * 2u;
+    }
+    const unsigned chunk_b = (unsigned)(PW_ROWS * a.ldx) * 2u;
+    auto issue_chunk = [&](int c) {
+        // (a chunk past the range, or rows past M: the descriptor's range check returns zeros, nothing is skipped, so every
+        // iteration issues the same number of memory operations and the counted waits below hold)
+        char* base = smem + (c & (PW_NSTG - 1)) * PW_CHUNKB + wave * 2048;
+        const unsigned long long off = (unsigned long long)c * chunk_b;
+        const bool ok = c < c_hi && off < 0x7fffffffull;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) buf_dma16(rx, base + i * 1024, ok ? dvo[i] + (unsigned)off : OOB);
+    };
+    // fragment read offsets: row l31, unit 2 ks + hh -> group ks >> 2 (immediate), low bits swizzled
+    int xr[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) xr[k4] = l31 * PW_ROWB + (((2 * k4 + hh) ^ (l31 >> 1)) & 7) * 16;
+
+    const int col0 = 32 * wave + 8 * hh;  // after the permlane32 swap a lane owns couts col0 + 16 p .. + 7 of its pixel
+    auto res_load = [&](int c, u32x4* r) {
+        const long long m = (long long)c * PW_ROWS + l31;
+        const bool ok = RES && c < c_hi && m < a.M;
+        const __bf16* rp = a.res + (ok ? m : 0) * a.ldres + col0;
+        r[0] = ok ? *(const u32x4*)rp : u32x4{0u, 0u, 0u, 0u};
+        r[1] = ok ? *(const u32x4*)(rp + 16) : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto swap32 = [](unsigned& lo, unsigned& hi) {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    };
+
+    u32x4 rc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if constexpr (RES) res_load(c_lo, rc);
+    issue_chunk(c_lo);
+    issue_chunk(c_lo + 1);
+    issue_chunk(c_lo + 2);
+    // all three landed: the counted wait of the loop assumes three iterations of younger operations behind the DMA it waits for
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        // memory operations of an iteration, in issue order: residual rows of chunk c + 1 (RES), DMA of chunk c + 3, stores of
+        // chunk c.  The residual is issued first so that waiting for it (next iteration) never waits for the newest DMAs.
+        u32x4 rn[2];
+        if constexpr (RES) res_load(c + 1, rn);
+        issue_chunk(c + 3);
+        const char* xb = smem + (c & (PW_NSTG - 1)) * PW_CHUNKB;
+        f32x16 acc = bq;
+#pragma unroll
+        for (int ks = 0; ks < PW_C / 16; ++ks) {
+            const bf16x8 xf = *(const bf16x8*)(xb + xr[ks & 3] + (ks >> 2) * 128);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+        }
+        const long long m = (long long)c * PW_ROWS + l31;
+        __bf16* orow = a.out + m * a.ldo + col0;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            float w8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned lo = __float_as_uint(acc[8 * p2 + e]), hi = __float_as_uint(acc[8 * p2 + 4 + e]);
+                swap32(lo, hi);
+                w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
+            }
+            if constexpr (RES) {
+                float r8[8];
+                unpack8(rc[p2], r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w8[e] += r8[e];
+            }
+            if (m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
+        }
+        if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
+        // chunk c + 1 must have landed: younger than its DMAs are (RES: 2 loads +) 2 DMAs + 2 stores per iteration since
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RES ? 14 : 10) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
 // ---------------------------------------------------------------- profiling hooks
 struct ProfRec { hipEvent_t e0, e1; double flops; int M, Cout, K, R, flags; };
 bool g_prof_on = false;       // benchmark hook (bench.py): while on, launches are serialised on g_prof_mu
@@ -711,6 +842,32 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
+
+int g_pw320 = 1;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel
+
+// CCNET_OK + *done = true if the problem is one of these layers and was launched here
+int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
+    *done = false;
+    if (!g_pw320 || g_force_cfg >= 0 || g_force_splitk) return CCNET_OK;
+    if (p->R != 1 || p->C1 != PW_C || p->C2 != 0 || p->Cout != PW_C || p->stride != 1 || p->ups != 1 || p->pad != 0) return CCNET_OK;
+    if (p->act != 0 || p->scale != 1.0f || p->rowvec || p->out2 || p->rowstat || p->stat_out || p->batch > 1) return CCNET_OK;
+    if (p->Hin != p->Hout || p->Win != p->Wout || M < 65536) return CCNET_OK;
+    const long long xb = ((long long)M - 1) * p->ldx1 * 2 + PW_ROWB;
+    if (xb >= 0x7fffffffLL) return CCNET_OK;
+    PwArgs a{};
+    a.x = (const __bf16*)p->x1; a.w = (const __bf16*)p->w; a.bias = p->bias; a.res = (const __bf16*)p->res1; a.out = (__bf16*)p->out;
+    a.M = M; a.ldx = p->ldx1; a.ldw = p->ldw; a.ldres = p->ldres1; a.ldo = p->ldo;
+    a.chunks = (M + PW_ROWS - 1) / PW_ROWS;
+    a.chunks_per_block = (a.chunks + kNumCUs - 1) / kNumCUs;
+    a.x_bytes = (unsigned)xb;
+    const int grid = (a.chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+    if (p->res1) hipLaunchKernelGGL(pw320_kernel<true>, dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
+    else hipLaunchKernelGGL(pw320_kernel<false>, dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return CCNET_ELAUNCH;
+    *done = true;
+    return CCNET_OK;
+}
+
 
 template <int WM, int WN, int TJ, int TI, bool GEGLU, int NS = 2, int BK = 64, bool SPLIT = false, bool PERSIST = false,
           bool RESPRE = false, bool STAT = false>
@@ -878,6 +1035,7 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 4) { g_persist = value; return CCNET_OK; }
     if (key == 6) { g_gn_onepass = value; return CCNET_OK; }
     if (key == 7) { g_attn_mode = value; return CCNET_OK; }
+    if (key == 8) { g_pw320 = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
@@ -1045,6 +1203,14 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
         rec->flags = (p->stride == 2) | ((p->ups == 2) << 1) | ((p->C2 > 0) << 2) | ((p->act == 2) << 3) |
                      ((p->res1 != nullptr) << 4) | ((p->out2 != nullptr) << 5) | ((batch > 1) << 6);
         (void)hipEventRecord(rec->e0, st);
+    }
+    {
+        bool done = false;
+        const int rc = try_pw320(p, a.M, st, &done);
+        if (rc != CCNET_OK || done) {
+            if (rec) (void)hipEventRecord(rec->e1, st);
+            return rc;
+        }
     }
     const bool geglu = p->act == 2;
     // a caller that brings no workspace gets the best unsplit plan (slower on deep-K, few-tile problems, never an error);

@@ -78,6 +78,35 @@ def test_conv_gemm(cuda, case):
     _close(_nchw(out), ref, atol=2e-2, what=f"conv {case}")
 
 
+@pytest.mark.parametrize("case", [(16, 64, True, 0), (17, 64, False, 0), (16, 64, True, 64), (20, 60, True, 0)])
+def test_pointwise_320_streaming_kernel(cuda, case):
+    """320 -> 320 1x1 layers of the 64x64 level run on the weight-stationary streaming kernel (weights in registers, pixel rows
+    through an LDS ring): bit-identical to the tiled kernel (ccnet_set_option(8, 0)), within tolerance of conv2d.  Cases: with /
+    without residual, a row count that is not a whole number of chunks per block, inputs that are column views of wider rows."""
+    ops = _ops()
+    from ccnet_amd import lib as L
+    from ccnet_amd.ops import Act
+    N, H, with_res, extra = case
+    g = torch.Generator().manual_seed(71)
+    M = N * H * H
+    wide = (torch.randn(M, 320 + extra, generator=g)).to(torch.bfloat16).to(cuda)
+    x = Act(wide[:, extra:], N, H, H, 320)
+    res = Act((torch.randn(M, 320 + extra, generator=g)).to(torch.bfloat16).to(cuda)[:, :320], N, H, H, 320) if with_res else None
+    w = (torch.randn(320, 320, generator=g) / math.sqrt(320)).to(torch.bfloat16).to(cuda)
+    b = torch.randn(320, generator=g).to(cuda)
+    out = ops.conv(x, w, b, 320, R=1, pad=0, res1=res)
+    assert L.load().ccnet_set_option(8, 0) == 0
+    try:
+        tiled = ops.conv(x, w, b, 320, R=1, pad=0, res1=res)
+    finally:
+        L.load().ccnet_set_option(8, 1)
+    assert torch.equal(out.t, tiled.t), f"streaming vs tiled kernel differ: max {(out.t.float() - tiled.t.float()).abs().max().item()}"
+    ref = x.t.float() @ w.float().T + b
+    if with_res:
+        ref = ref + res.t.float()
+    _close(out.t.float(), ref, atol=2e-2, what=f"pointwise 320 {case}")
+
+
 def test_conv_epilogue_full(cuda):
     """bias + per-image rowvec + SiLU + scale + residual + dual output in one launch."""
     ops = _ops()
