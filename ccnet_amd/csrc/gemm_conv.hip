@@ -707,23 +707,31 @@ constexpr int PW_C = 320, PW_WAVES = PW_C / 32, PW_ROWS = 32, PW_NSTG = 4, PW_RO
 struct PwArgs {
     const __bf16* x; const __bf16* w; const float* bias; const __bf16* res; __bf16* out;
     int M, ldx, ldw, ldres, ldo, chunks, chunks_per_block;
+    int G;  // cout groups of 320 (Cout = 320 G): G blocks walk the same row range, one group each
     unsigned x_bytes;
 };
 
-template <bool RES>
+// Cout = 320 G (qkv: G = 3, ff.linear1 + GEGLU: G = 8): block id = xcd + 8 g + 8 G rr handles cout group g of row range
+// 8 rr + xcd, so the G blocks of a range sit on one XCD, are dispatched together and move at the same pace: the range's rows
+// come from HBM once and from that XCD's L2 for the other G - 1 groups.
+// GEGLU: the wave's 32 weight rows are 8-row value / gate blocks (ops.geglu_interleave); it writes 16 outputs per pixel.
+template <bool RES, bool GEGLU>
 __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a) {
+    static_assert(!(RES && GEGLU), "GEGLU layers carry no residual");
     __shared__ __attribute__((aligned(1024))) char smem[PW_NSTG * PW_CHUNKB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int c_lo = blockIdx.x * a.chunks_per_block;
+    const int bt = blockIdx.x >> 3, grp = bt % a.G, range = (bt / a.G) * 8 + (blockIdx.x & 7);
+    const int c_lo = range * a.chunks_per_block;
     const int c_hi = min(c_lo + a.chunks_per_block, a.chunks);
     if (c_lo >= c_hi) return;  // (whole block: no barrier is pending)
+    const int n0 = PW_C * grp;  // first cout of the block's group
 
     // the wave's weight fragments: lane holds W[32 wave + l31][16 ks + 8 hh .. + 7]
     bf16x8 wf[PW_C / 16];
     {
-        const __bf16* wp = a.w + (long long)(32 * wave + l31) * a.ldw + 8 * hh;
+        const __bf16* wp = a.w + (long long)(n0 + 32 * wave + l31) * a.ldw + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < PW_C / 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wp + 16 * ks));
     }
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
     f32x16 bq;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 t = a.bias ? *(const f32x4*)(a.bias + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 t = a.bias ? *(const f32x4*)(a.bias + n0 + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) bq[4 * q + e] = t[e];
     }
@@ -762,7 +770,8 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) xr[k4] = l31 * PW_ROWB + (((2 * k4 + hh) ^ (l31 >> 1)) & 7) * 16;
 
-    const int col0 = 32 * wave + 8 * hh;  // after the permlane32 swap a lane owns couts col0 + 16 p .. + 7 of its pixel
+    // after the permlane32 swap a lane owns couts col0 + 16 p .. + 7 of its pixel (GEGLU: outputs col0 .. + 7, half as many)
+    const int col0 = GEGLU ? (n0 + 32 * wave) / 2 + 8 * hh : n0 + 32 * wave + 8 * hh;
     auto res_load = [&](int c, u32x4* r) {
         const long long m = (long long)c * PW_ROWS + l31;
         const bool ok = RES && c < c_hi && m < a.M;
@@ -800,6 +809,23 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
         }
         const long long m = (long long)c * PW_ROWS + l31;
         __bf16* orow = a.out + m * a.ldo + col0;
+        if constexpr (GEGLU) {
+            // quads (0, 1) -> outputs 4 hh + e, quads (2, 3) -> outputs 8 + 4 hh + e of the wave's 16 (conv_gemm_kernel's form)
+            float r8[8];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const f32x2 r = geglu_pk(f32x2{acc[8 * h2 + e], acc[8 * h2 + e + 1]}, f32x2{acc[8 * h2 + 4 + e], acc[8 * h2 + 5 + e]});
+                    r8[4 * h2 + e] = r[0];
+                    r8[4 * h2 + e + 1] = r[1];
+                }
+            unsigned d0 = pack_bf16x2(r8[0], r8[1]), d1 = pack_bf16x2(r8[2], r8[3]);
+            unsigned d2 = pack_bf16x2(r8[4], r8[5]), d3 = pack_bf16x2(r8[6], r8[7]);
+            swap32(d0, d2);
+            swap32(d1, d3);
+            if (m < a.M) *(u32x4*)orow = u32x4{d0, d1, d2, d3};
+        } else
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
             float w8[8];
@@ -819,7 +845,8 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
         }
         if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
         // chunk c + 1 must have landed: younger than its DMAs are (RES: 2 loads +) 2 DMAs + 2 stores per iteration since
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RES ? 14 : 10) : "memory");
+        // (GEGLU: one store per iteration)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RES ? 14 : GEGLU ? 7 : 10) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -843,26 +870,32 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
-int g_pw320 = 1;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel
+int g_pw320 = 7;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: Cout = 320 G too; bit 2: GEGLU too
 
 // CCNET_OK + *done = true if the problem is one of these layers and was launched here
 int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     *done = false;
     if (!g_pw320 || g_force_cfg >= 0 || g_force_splitk) return CCNET_OK;
-    if (p->R != 1 || p->C1 != PW_C || p->C2 != 0 || p->Cout != PW_C || p->stride != 1 || p->ups != 1 || p->pad != 0) return CCNET_OK;
-    if (p->act != 0 || p->scale != 1.0f || p->rowvec || p->out2 || p->rowstat || p->stat_out || p->batch > 1) return CCNET_OK;
+    if (p->R != 1 || p->C1 != PW_C || p->C2 != 0 || (p->Cout % PW_C) || p->stride != 1 || p->ups != 1 || p->pad != 0) return CCNET_OK;
+    const int G = p->Cout / PW_C;
+    if (G > 8 || (G > 1 && !(g_pw320 & 2))) return CCNET_OK;
+    if ((p->act != 0 && p->act != 2) || (p->act == 2 && (p->res1 || !(g_pw320 & 4)))) return CCNET_OK;
+    if (p->scale != 1.0f || p->rowvec || p->out2 || p->rowstat || p->stat_out || p->batch > 1) return CCNET_OK;
     if (p->Hin != p->Hout || p->Win != p->Wout || M < 65536) return CCNET_OK;
     const long long xb = ((long long)M - 1) * p->ldx1 * 2 + PW_ROWB;
     if (xb >= 0x7fffffffLL) return CCNET_OK;
     PwArgs a{};
     a.x = (const __bf16*)p->x1; a.w = (const __bf16*)p->w; a.bias = p->bias; a.res = (const __bf16*)p->res1; a.out = (__bf16*)p->out;
-    a.M = M; a.ldx = p->ldx1; a.ldw = p->ldw; a.ldres = p->ldres1; a.ldo = p->ldo;
+    a.M = M; a.ldx = p->ldx1; a.ldw = p->ldw; a.ldres = p->ldres1; a.ldo = p->ldo; a.G = G;
     a.chunks = (M + PW_ROWS - 1) / PW_ROWS;
-    a.chunks_per_block = (a.chunks + kNumCUs - 1) / kNumCUs;
+    // row ranges: a multiple of 8 (one per XCD slot), ranges x G blocks a whole number of rounds of the chip where possible
+    const int ranges = G >= 8 ? kNumCUs / 2 : kNumCUs;
+    a.chunks_per_block = (a.chunks + ranges - 1) / ranges;
     a.x_bytes = (unsigned)xb;
-    const int grid = (a.chunks + a.chunks_per_block - 1) / a.chunks_per_block;
-    if (p->res1) hipLaunchKernelGGL(pw320_kernel<true>, dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
-    else hipLaunchKernelGGL(pw320_kernel<false>, dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
+    const int grid = ranges * G;
+    if (p->act == 2) hipLaunchKernelGGL((pw320_kernel<false, true>), dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
+    else if (p->res1) hipLaunchKernelGGL((pw320_kernel<true, false>), dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
+    else hipLaunchKernelGGL((pw320_kernel<false, false>), dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
     if (hipGetLastError() != hipSuccess) return CCNET_ELAUNCH;
     *done = true;
     return CCNET_OK;
