@@ -285,7 +285,7 @@ def main():
         traffic = hbm_traffic_per_launch()
         alg_per_launch = alg_bytes / max(launches, 1)
         tb = (traffic or {}).get("bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "ccnet_conv_gemm_bf16 launches: conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA) + pw320_kernel (its streaming instance for the K = 320 pointwise layers)",
+        roof = {"bound": "mfma", "kernel": "ccnet_conv_gemm_bf16 launches: conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA) + pw_stream_kernel (its streaming instance for the K = 320 pointwise layers)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tb,
                 "traffic_unit": "bytes per launch crossing the L2 -> fabric boundary (HBM + Infinity Cache), PMC passes "

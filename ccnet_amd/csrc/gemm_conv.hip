@@ -694,31 +694,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- 320 -> 320 pointwise layers of the 64x64 level
-// o-proj (+ residual), proj_in / proj_out (+ residual), attn2.to_q at 320 channels: K = 320 gives 160 FLOP per byte, far
-// below the machine balance, and in the tiled kernel a CU alternates between a K loop (HBM idle) and an epilogue (matrix
-// core idle): 2.8-3.0 TB/s of algorithmic traffic.  Here the WEIGHTS never move: a block is 10 waves, wave w keeps the A
-// fragments of couts 32 w .. 32 w + 31 for the whole K = 320 in 80 registers, and the block streams its share of the pixel
-// rows in chunks of 32 through a ring of four LDS stages (LDS-DMA, 20 KB per chunk, issued three chunks ahead).  Per chunk a
-// wave does 20 MFMAs (B fragments = the chunk's rows, shared by all ten waves), adds the residual rows it prefetched one
-// chunk earlier and stores 32 x 32 outputs -- loads, MFMAs and stores of neighbouring chunks overlap all the time, there is
-// no tile epilogue.  Results are bit-identical to the tiled kernel (same k order, accumulators start at the bias).
-constexpr int PW_C = 320, PW_WAVES = PW_C / 32, PW_ROWS = 32, PW_NSTG = 4, PW_ROWB = PW_C * 2, PW_CHUNKB = PW_ROWS * PW_ROWB;
+// ---------------------------------------------------------------- pointwise layers with 320 / 640 input channels
+// o-proj (+ residual), proj_in / proj_out (+ residual), attn2.to_q, qkv, ff.linear1 + GEGLU at the 64x64 (320 channels) and
+// 32x32 (640 channels) levels: K = 320 gives 160 FLOP per byte, far below the machine balance, and in the tiled kernel a CU
+// alternates between a K loop (HBM idle) and an epilogue (matrix core idle): 2.2-3.0 TB/s of algorithmic traffic.  Here the
+// WEIGHTS never move: a block is WAVES waves, wave w keeps the A fragments of couts 32 w .. 32 w + 31 of the block's cout
+// group for the whole K in registers (80 at K = 320, ten waves = 320 couts; 160 at K = 640, four waves = 128 couts), and the
+// block streams its row range in chunks of 32 rows through a ring of NSTG LDS stages (LDS-DMA, NSTG - 1 chunks ahead).  Per
+// chunk a wave does K / 16 MFMAs (B fragments = the chunk's rows, shared by all waves), adds the residual rows it prefetched
+// one chunk earlier and stores 32 x 32 outputs -- loads, MFMAs and stores of neighbouring chunks overlap all the time, there
+// is no tile epilogue.  Results are bit-identical to the tiled kernel (same k order, accumulators start at the bias).
+// Cout = GW G (GW = 32 WAVES couts per block): block id = xcd + 8 g + 8 G rr handles cout group g of row range 8 rr + xcd, so
+// the G blocks of a range sit on one XCD, are dispatched together and move at the same pace: the range's rows come from
+// HBM once and from that XCD's L2 for the other G - 1 groups.
+// GEGLU: the wave's 32 weight rows are 8-row value / gate blocks (ops.geglu_interleave); it writes 16 outputs per pixel.
+constexpr int PW_ROWS = 32;
 struct PwArgs {
     const __bf16* x; const __bf16* w; const float* bias; const __bf16* res; __bf16* out;
     int M, ldx, ldw, ldres, ldo, chunks, chunks_per_block;
-    int G;  // cout groups of 320 (Cout = 320 G): G blocks walk the same row range, one group each
+    int G;  // cout groups (Cout = 32 WAVES G): G blocks walk the same row range, one group each
     unsigned x_bytes;
 };
 
-// Cout = 320 G (qkv: G = 3, ff.linear1 + GEGLU: G = 8): block id = xcd + 8 g + 8 G rr handles cout group g of row range
-// 8 rr + xcd, so the G blocks of a range sit on one XCD, are dispatched together and move at the same pace: the range's rows
-// come from HBM once and from that XCD's L2 for the other G - 1 groups.
-// GEGLU: the wave's 32 weight rows are 8-row value / gate blocks (ops.geglu_interleave); it writes 16 outputs per pixel.
-template <bool RES, bool GEGLU>
-__global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a) {
+template <int C, int WAVES, int NSTG, bool RES, bool GEGLU>
+__global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a) {
     static_assert(!(RES && GEGLU), "GEGLU layers carry no residual");
-    __shared__ __attribute__((aligned(1024))) char smem[PW_NSTG * PW_CHUNKB];
+    static_assert(C == 320 || C == 640, "row swizzle below: 40 or 80 16-byte units per row");
+    constexpr int ROWB = C * 2, CHUNKB = PW_ROWS * ROWB, UPR = C / 8;      // bytes per row / chunk, 16-byte units per row
+    constexpr int PIECES = CHUNKB / 1024, PPW = PIECES / WAVES;             // 1-KiB DMA pieces per chunk / per wave
+    static_assert(PIECES % WAVES == 0, "DMA pieces divide over the waves");
+    constexpr int KS = C / 16, GW = 32 * WAVES;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];           // NSTG chunks
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -726,16 +732,16 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
     const int c_lo = range * a.chunks_per_block;
     const int c_hi = min(c_lo + a.chunks_per_block, a.chunks);
     if (c_lo >= c_hi) return;  // (whole block: no barrier is pending)
-    const int n0 = PW_C * grp;  // first cout of the block's group
+    const int n0 = GW * grp;   // first cout of the block's group
 
-    // the wave's weight fragments: lane holds W[32 wave + l31][16 ks + 8 hh .. + 7]
-    bf16x8 wf[PW_C / 16];
+    // the wave's weight fragments: lane holds W[n0 + 32 wave + l31][16 ks + 8 hh .. + 7]
+    bf16x8 wf[KS];
     {
         const __bf16* wp = a.w + (long long)(n0 + 32 * wave + l31) * a.ldw + 8 * hh;
 #pragma unroll
-        for (int ks = 0; ks < PW_C / 16; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wp + 16 * ks));
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wp + 16 * ks));
     }
-    // accumulator start: bias of couts 32 wave + 8 q + 4 hh + e
+    // accumulator start: bias of couts n0 + 32 wave + 8 q + 4 hh + e
     f32x16 bq;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -746,29 +752,28 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
     __builtin_amdgcn_sched_barrier(0);
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-    // DMA: a chunk is 20 pieces of 64 16-byte units (40 units per row); wave w brings pieces 2 w, 2 w + 1.  The unit that
-    // lands at position p of row r is unit (p & ~7) | ((p ^ (r >> 1)) & 7) of that row: conflict-free ds_read_b128 below.
-    unsigned dvo[2];
+    // Row swizzle: the unit at position p of row r is unit p ^ swz(r) of that row, swz(r) = (r >> 1) & 7 for 40 units per row
+    // (rows alternate between the two halves of the 16 bank groups by themselves), + ((r & 1) << 3) for 80 (they do not):
+    // the 16 rows that one ds_read_b128 phase covers hit 16 different bank groups.
+    auto swz = [](int r) { return C == 320 ? ((r >> 1) & 7) : (((r >> 1) & 7) | ((r & 1) << 3)); };
+    unsigned dvo[PPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = (2 * wave + i) * 64 + lane, r = u / 40, pp = u - r * 40;
-        const int unit = (pp & ~7) | ((pp ^ (r >> 1)) & 7);
-        dvo[i] = (unsigned)(r * a.ldx + unit * 8) * 2u;
+    for (int i = 0; i < PPW; ++i) {
+        const int u = (PPW * wave + i) * 64 + lane, r = u / UPR, pp = u - r * UPR;
+        dvo[i] = (unsigned)(r * a.ldx + (pp ^ swz(r)) * 8) * 2u;
     }
     const unsigned chunk_b = (unsigned)(PW_ROWS * a.ldx) * 2u;
     auto issue_chunk = [&](int c) {
         // (a chunk past the range, or rows past M: the descriptor's range check returns zeros, nothing is skipped, so every
         // iteration issues the same number of memory operations and the counted waits below hold)
-        char* base = smem + (c & (PW_NSTG - 1)) * PW_CHUNKB + wave * 2048;
+        char* base = smem + (c % NSTG) * CHUNKB + wave * (PPW * 1024);
         const unsigned long long off = (unsigned long long)c * chunk_b;
         const bool ok = c < c_hi && off < 0x7fffffffull;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) buf_dma16(rx, base + i * 1024, ok ? dvo[i] + (unsigned)off : OOB);
+        for (int i = 0; i < PPW; ++i) buf_dma16(rx, base + i * 1024, ok ? dvo[i] + (unsigned)off : OOB);
     };
-    // fragment read offsets: row l31, unit 2 ks + hh -> group ks >> 2 (immediate), low bits swizzled
-    int xr[4];
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) xr[k4] = l31 * PW_ROWB + (((2 * k4 + hh) ^ (l31 >> 1)) & 7) * 16;
+    // fragment read: row l31, unit (2 ks + hh) ^ swz(l31) = (2 ks) ^ (hh ^ swz(l31)): a lane constant XOR a literal
+    const int xrow = l31 * ROWB, xsw = (hh ^ swz(l31)) << 4;
 
     // after the permlane32 swap a lane owns couts col0 + 16 p .. + 7 of its pixel (GEGLU: outputs col0 .. + 7, half as many)
     const int col0 = GEGLU ? (n0 + 32 * wave) / 2 + 8 * hh : n0 + 32 * wave + 8 * hh;
@@ -786,25 +791,24 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
 
     u32x4 rc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     if constexpr (RES) res_load(c_lo, rc);
-    issue_chunk(c_lo);
-    issue_chunk(c_lo + 1);
-    issue_chunk(c_lo + 2);
-    // all three landed: the counted wait of the loop assumes three iterations of younger operations behind the DMA it waits for
+#pragma unroll
+    for (int i = 0; i < NSTG - 1; ++i) issue_chunk(c_lo + i);
+    // all landed: the counted wait of the loop assumes NSTG - 2 whole iterations of younger operations behind the DMA it waits for
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     for (int c = c_lo; c < c_hi; ++c) {
-        // memory operations of an iteration, in issue order: residual rows of chunk c + 1 (RES), DMA of chunk c + 3, stores of
-        // chunk c.  The residual is issued first so that waiting for it (next iteration) never waits for the newest DMAs.
+        // memory operations of an iteration, in issue order: residual rows of chunk c + 1 (RES), DMA of chunk c + NSTG - 1, stores
+        // of chunk c.  The residual is issued first so that waiting for it (next iteration) never waits for the newest DMAs.
         u32x4 rn[2];
         if constexpr (RES) res_load(c + 1, rn);
-        issue_chunk(c + 3);
-        const char* xb = smem + (c & (PW_NSTG - 1)) * PW_CHUNKB;
+        issue_chunk(c + NSTG - 1);
+        const char* xb = smem + (c % NSTG) * CHUNKB + xrow;
         f32x16 acc = bq;
 #pragma unroll
-        for (int ks = 0; ks < PW_C / 16; ++ks) {
-            const bf16x8 xf = *(const bf16x8*)(xb + xr[ks & 3] + (ks >> 2) * 128);
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 xf = *(const bf16x8*)(xb + (((2 * ks) << 4) ^ xsw));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
         }
         const long long m = (long long)c * PW_ROWS + l31;
@@ -844,9 +848,10 @@ __global__ __launch_bounds__(64 * PW_WAVES, 1) void pw320_kernel(const PwArgs a)
             if (m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
         }
         if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
-        // chunk c + 1 must have landed: younger than its DMAs are (RES: 2 loads +) 2 DMAs + 2 stores per iteration since
-        // (GEGLU: one store per iteration)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RES ? 14 : GEGLU ? 7 : 10) : "memory");
+        // chunk c + 1 must have landed.  Younger than its DMAs (issued NSTG - 2 iterations ago): that iteration's stores and
+        // NSTG - 2 whole iterations of (residual loads +) DMAs + stores
+        constexpr int ST = GEGLU ? 1 : 2, PER = (RES ? 2 : 0) + PPW + ST;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST + (NSTG - 2) * PER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -870,33 +875,56 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
-int g_pw320 = 7;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: Cout = 320 G too; bit 2: GEGLU too
+int g_pw320 = 7;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: several cout groups too;
+                  // bit 2: GEGLU too
 
 // CCNET_OK + *done = true if the problem is one of these layers and was launched here
+template <int C, int WAVES, int NSTG, bool RES, bool GEGLU>
+int launch_pw(const PwArgs& a, int grid, hipStream_t st) {
+    constexpr int LDS = NSTG * PW_ROWS * C * 2;
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)pw_stream_kernel<C, WAVES, NSTG, RES, GEGLU>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return CCNET_ELAUNCH;
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((pw_stream_kernel<C, WAVES, NSTG, RES, GEGLU>), dim3(grid), dim3(64 * WAVES), LDS, st, a);
+    return hipGetLastError() == hipSuccess ? CCNET_OK : CCNET_ELAUNCH;
+}
+
 int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     *done = false;
     if (!g_pw320 || g_force_cfg >= 0 || g_force_splitk) return CCNET_OK;
-    if (p->R != 1 || p->C1 != PW_C || p->C2 != 0 || (p->Cout % PW_C) || p->stride != 1 || p->ups != 1 || p->pad != 0) return CCNET_OK;
-    const int G = p->Cout / PW_C;
+    if (p->R != 1 || p->C2 != 0 || p->stride != 1 || p->ups != 1 || p->pad != 0) return CCNET_OK;
+    // 640 input channels (four waves of 160 weight registers, 128 couts per block, ring of three 40 KB stages) were built and
+    // measured at the 32x32 level: 43 / 51 / 111 / 300 us against the tiled kernel's 37 / 44 / 104 / 264 (proj, o-proj + res, qkv,
+    // ff1 + GEGLU) -- one wave per SIMD does not keep the matrix core busy and M = 32768 rows amortise the 164 KB weight
+    // prologue badly -- so only the 320-channel level runs here.
+    if (p->C1 != 320) return CCNET_OK;
+    const int GW = 320;  // couts per block
+    if (p->Cout % GW) return CCNET_OK;
+    const int G = p->Cout / GW;
     if (G > 8 || (G > 1 && !(g_pw320 & 2))) return CCNET_OK;
     if ((p->act != 0 && p->act != 2) || (p->act == 2 && (p->res1 || !(g_pw320 & 4)))) return CCNET_OK;
     if (p->scale != 1.0f || p->rowvec || p->out2 || p->rowstat || p->stat_out || p->batch > 1) return CCNET_OK;
     if (p->Hin != p->Hout || p->Win != p->Wout || M < 65536) return CCNET_OK;
-    const long long xb = ((long long)M - 1) * p->ldx1 * 2 + PW_ROWB;
+    const long long xb = ((long long)M - 1) * p->ldx1 * 2 + p->C1 * 2;
     if (xb >= 0x7fffffffLL) return CCNET_OK;
     PwArgs a{};
     a.x = (const __bf16*)p->x1; a.w = (const __bf16*)p->w; a.bias = p->bias; a.res = (const __bf16*)p->res1; a.out = (__bf16*)p->out;
     a.M = M; a.ldx = p->ldx1; a.ldw = p->ldw; a.ldres = p->ldres1; a.ldo = p->ldo; a.G = G;
     a.chunks = (M + PW_ROWS - 1) / PW_ROWS;
-    // row ranges: a multiple of 8 (one per XCD slot), ranges x G blocks a whole number of rounds of the chip where possible
-    const int ranges = G >= 8 ? kNumCUs / 2 : kNumCUs;
+    // row ranges: a multiple of 8 (one per XCD slot), ranges x G blocks fill one round of the chip
+    // (one round of 8 floor(256 / 8 G) x G blocks measured 2-4 % faster than 256 or 128 ranges in three or four rounds: fewer
+    // weight prologues)
+    const int ranges = 8 * (kNumCUs / (8 * G));
     a.chunks_per_block = (a.chunks + ranges - 1) / ranges;
     a.x_bytes = (unsigned)xb;
     const int grid = ranges * G;
-    if (p->act == 2) hipLaunchKernelGGL((pw320_kernel<false, true>), dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
-    else if (p->res1) hipLaunchKernelGGL((pw320_kernel<true, false>), dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
-    else hipLaunchKernelGGL((pw320_kernel<false, false>), dim3(grid), dim3(64 * PW_WAVES), 0, st, a);
-    if (hipGetLastError() != hipSuccess) return CCNET_ELAUNCH;
+    const int rc = p->act == 2 ? launch_pw<320, 10, 4, false, true>(a, grid, st)
+                 : p->res1 ? launch_pw<320, 10, 4, true, false>(a, grid, st) : launch_pw<320, 10, 4, false, false>(a, grid, st);
+    if (rc != CCNET_OK) return rc;
     *done = true;
     return CCNET_OK;
 }

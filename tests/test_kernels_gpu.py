@@ -78,25 +78,26 @@ def test_conv_gemm(cuda, case):
     _close(_nchw(out), ref, atol=2e-2, what=f"conv {case}")
 
 
-@pytest.mark.parametrize("case", [(16, 64, True, 0, 320, 0), (17, 64, False, 0, 320, 0), (16, 64, True, 64, 320, 0),
-                                  (20, 60, True, 0, 320, 0), (16, 64, False, 0, 960, 0), (17, 64, True, 0, 960, 0),
-                                  (16, 64, False, 0, 2560, 2), (18, 64, False, 64, 2560, 2)])
-def test_pointwise_320_streaming_kernel(cuda, case):
-    """320 -> 320 G 1x1 layers of the 64x64 level (o-proj / proj_in / proj_out / to_q, qkv, ff.linear1 + GEGLU) run on the
-    weight-stationary streaming kernel (weights in registers, pixel rows through an LDS ring): bit-identical to the tiled kernel
-    (ccnet_set_option(8, 0)), within tolerance of the fp32 product.  Cases: with / without residual, row counts that are not a
-    whole number of chunks per block, inputs that are column views of wider rows, three and eight cout groups, GEGLU."""
+@pytest.mark.parametrize("case", [(16, 64, True, 0, 320, 0, 320), (17, 64, False, 0, 320, 0, 320), (16, 64, True, 64, 320, 0, 320),
+                                  (20, 60, True, 0, 320, 0, 320), (16, 64, False, 0, 960, 0, 320), (17, 64, True, 0, 960, 0, 320),
+                                  (16, 64, False, 0, 2560, 2, 320), (18, 64, False, 64, 2560, 2, 320)])
+def test_pointwise_streaming_kernel(cuda, case):
+    """1x1 layers with 320 input channels at the 64x64 level (o-proj / proj_in / proj_out / to_q, qkv, ff.linear1 +
+    GEGLU) run on the weight-stationary streaming kernel (weights in registers, pixel rows through an LDS ring): bit-identical
+    to the tiled kernel (ccnet_set_option(8, 0)), within tolerance of the fp32 product.  Cases: with / without residual, row
+    counts that are not a whole number of chunks per block, inputs that are column views of wider rows, several cout groups,
+    GEGLU."""
     ops = _ops()
     from ccnet_amd import lib as L
     from ccnet_amd.ops import Act
-    N, H, with_res, extra, Cout, act = case
+    N, H, with_res, extra, Cout, act, Cin = case
     g = torch.Generator().manual_seed(71)
     M = N * H * H
     Co = Cout // 2 if act == 2 else Cout
-    wide = (torch.randn(M, 320 + extra, generator=g)).to(torch.bfloat16).to(cuda)
-    x = Act(wide[:, extra:], N, H, H, 320)
+    wide = (torch.randn(M, Cin + extra, generator=g)).to(torch.bfloat16).to(cuda)
+    x = Act(wide[:, extra:], N, H, H, Cin)
     res = Act((torch.randn(M, Co + extra, generator=g)).to(torch.bfloat16).to(cuda)[:, :Co], N, H, H, Co) if with_res else None
-    w = (torch.randn(Cout, 320, generator=g) / math.sqrt(320)).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin)).to(torch.bfloat16)
     b = torch.randn(Cout, generator=g)
     wk, bk = (ops.geglu_interleave(w), ops.geglu_interleave(b)) if act == 2 else (w, b)
     wk, bk = wk.contiguous().to(cuda), bk.contiguous().to(cuda)
@@ -112,7 +113,7 @@ def test_pointwise_320_streaming_kernel(cuda, case):
         ref = ref[:, :Co] * F.gelu(ref[:, Co:])
     if with_res:
         ref = ref + res.t.float()
-    _close(out.t.float(), ref, atol=3e-2, what=f"pointwise 320 {case}")
+    _close(out.t.float(), ref, atol=3e-2, what=f"pointwise streaming {case}")
 
 
 def test_conv_epilogue_full(cuda):
