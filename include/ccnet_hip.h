@@ -244,7 +244,12 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t*
 /* ------------------------------------------------------------------ profiling hooks for bench.py
  * When enabled, ccnet_conv_gemm_bf16 brackets each launch with hipEvents on `stream`;
  * ccnet_prof_collect synchronises the events and returns summed kernel ms / FLOPs / launches. */
-int ccnet_set_option(int key, int value); /* key 0: conv operand staging, 1 = LDS-DMA (default), 0 = registers */
+/* Tuning switches for A/B timing (tools/, bench.py; CCNET_HIP_OPTIONS="key=value,..." sets them at load): key 0 forces a conv
+ * tile configuration (-1 = planned), 2 the tile order, 3 the split-K factor, 4 persistent launches (0 off, > 1 = K limit),
+ * 6 the one-pass GroupNorm paths, 7 the attention instance (0 by shape, 1 round-1 kernel, 2 long-key instance wherever it
+ * applies), 8 the streaming pointwise kernel (0 off; bits: 1 on, 2 several cout groups, 4 GEGLU).  Results do not depend on
+ * any of them beyond the order of fp32 sums inside a tile (the streaming kernel is bit-identical to the tiled one). */
+int ccnet_set_option(int key, int value);
 int ccnet_prof_enable(int on);
 int ccnet_prof_collect(double* ms, double* flops, int64_t* launches);
 /* per-shape table of the recorded launches: rows of 7 doubles {M, Cout, K, R, flags, launches, ms}; returns the row
