@@ -80,12 +80,13 @@ def test_conv_gemm(cuda, case):
 
 @pytest.mark.parametrize("case", [(16, 64, True, 0, 320, 0, 320), (17, 64, False, 0, 320, 0, 320), (16, 64, True, 64, 320, 0, 320),
                                   (20, 60, True, 0, 320, 0, 320), (16, 64, False, 0, 960, 0, 320), (17, 64, True, 0, 960, 0, 320),
-                                  (16, 64, False, 0, 2560, 2, 320), (18, 64, False, 64, 2560, 2, 320)])
+                                  (16, 64, False, 0, 2560, 2, 320), (18, 64, False, 64, 2560, 2, 320),
+                                  (17, 63, True, 0, 320, 0, 320), (17, 63, False, 0, 960, 0, 320), (17, 63, False, 0, 2560, 2, 320)])
 def test_pointwise_streaming_kernel(cuda, case):
     """1x1 layers with 320 input channels at the 64x64 level (o-proj / proj_in / proj_out / to_q, qkv, ff.linear1 +
     GEGLU) run on the weight-stationary streaming kernel (weights in registers, pixel rows through an LDS ring): bit-identical
     to the tiled kernel (ccnet_set_option(8, 0)), within tolerance of the fp32 product.  Cases: with / without residual, row
-    counts that are not a whole number of chunks per block, inputs that are column views of wider rows, several cout groups,
+    counts that are not a whole number of chunks per block or of 32-row chunks (67473 rows), inputs that are column views of wider rows, several cout groups,
     GEGLU."""
     ops = _ops()
     from ccnet_amd import lib as L
