@@ -712,7 +712,8 @@ constexpr int PW_ROWS = 32;
 struct PwArgs {
     const __bf16* x; const __bf16* w; const float* bias; const __bf16* res; __bf16* out;
     int M, ldx, ldw, ldres, ldo, chunks, chunks_per_block;
-    int G;  // cout groups (Cout = 32 WAVES G): G blocks walk the same row range, one group each
+    int G;  // cout groups (Cout <= 32 WAVES G): G blocks walk the same row range, one group each
+    int Cout;  // (GEGLU: rows of w; the last group may be partial: its waves beyond Cout only stage rows and meet the barriers)
     unsigned x_bytes;
 };
 
@@ -733,11 +734,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
     const int c_hi = min(c_lo + a.chunks_per_block, a.chunks);
     if (c_lo >= c_hi) return;  // (whole block: no barrier is pending)
     const int n0 = GW * grp;   // first cout of the block's group
+    const bool wact = n0 + 32 * wave < a.Cout;  // wave-uniform
 
     // the wave's weight fragments: lane holds W[n0 + 32 wave + l31][16 ks + 8 hh .. + 7]
     bf16x8 wf[KS];
     {
-        const __bf16* wp = a.w + (long long)(n0 + 32 * wave + l31) * a.ldw + 8 * hh;
+        const __bf16* wp = a.w + (long long)(wact ? n0 + 32 * wave + l31 : 0) * a.ldw + 8 * hh;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wp + 16 * ks));
     }
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
     f32x16 bq;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 t = a.bias ? *(const f32x4*)(a.bias + n0 + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 t = (a.bias && wact) ? *(const f32x4*)(a.bias + n0 + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) bq[4 * q + e] = t[e];
     }
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
     const int col0 = GEGLU ? (n0 + 32 * wave) / 2 + 8 * hh : n0 + 32 * wave + 8 * hh;
     auto res_load = [&](int c, u32x4* r) {
         const long long m = (long long)c * PW_ROWS + l31;
-        const bool ok = RES && c < c_hi && m < a.M;
+        const bool ok = RES && wact && c < c_hi && m < a.M;
         const __bf16* rp = a.res + (ok ? m : 0) * a.ldres + col0;
         r[0] = ok ? *(const u32x4*)rp : u32x4{0u, 0u, 0u, 0u};
         r[1] = ok ? *(const u32x4*)(rp + 16) : u32x4{0u, 0u, 0u, 0u};
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
             unsigned d2 = pack_bf16x2(r8[4], r8[5]), d3 = pack_bf16x2(r8[6], r8[7]);
             swap32(d0, d2);
             swap32(d1, d3);
-            if (m < a.M) *(u32x4*)orow = u32x4{d0, d1, d2, d3};
+            if (wact && m < a.M) *(u32x4*)orow = u32x4{d0, d1, d2, d3};
         } else
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
 #pragma unroll
                 for (int e = 0; e < 8; ++e) w8[e] += r8[e];
             }
-            if (m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
+            if (wact && m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
         }
         if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
         // chunk c + 1 must have landed.  Younger than its DMAs (issued NSTG - 2 iterations ago): that iteration's stores and
@@ -875,8 +877,8 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
-int g_pw320 = 7;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: several cout groups too;
-                  // bit 2: GEGLU too
+int g_pw320 = 15;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: several cout groups too;
+                   // bit 2: GEGLU too; bit 3: 640 input channels too (8 waves x 160 weight registers, 256 couts per block)
 
 // CCNET_OK + *done = true if the problem is one of these layers and was launched here
 template <int C, int WAVES, int NSTG, bool RES, bool GEGLU>
@@ -897,32 +899,36 @@ int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     *done = false;
     if (!g_pw320 || g_force_cfg >= 0 || g_force_splitk) return CCNET_OK;
     if (p->R != 1 || p->C2 != 0 || p->stride != 1 || p->ups != 1 || p->pad != 0) return CCNET_OK;
-    // 640 input channels (four waves of 160 weight registers, 128 couts per block, ring of three 40 KB stages) were built and
-    // measured at the 32x32 level: 43 / 51 / 111 / 300 us against the tiled kernel's 37 / 44 / 104 / 264 (proj, o-proj + res, qkv,
-    // ff1 + GEGLU) -- one wave per SIMD does not keep the matrix core busy and M = 32768 rows amortise the 164 KB weight
-    // prologue badly -- so only the 320-channel level runs here.
-    if (p->C1 != 320) return CCNET_OK;
-    const int GW = 320;  // couts per block
+    // 640 input channels (32x32 level): eight waves of 160 weight registers = 256 couts per block, ring of three 40 KB stages.
+    // Pays where many cout groups share the rows (qkv 1920: 101-109 -> 83 us, ff.linear1 + GEGLU 5120: 256-273 -> 226 us); for
+    // the 640-cout layers it does not (proj 44 -> 47 us, o-proj + res 43 -> 42: 2.5 groups padded to 3, 32768 rows per 328 KB
+    // weight prologue), nor did a four-wave form with 128 couts per block (one wave per SIMD): those stay on the tiled kernel.
+    const bool c640 = p->C1 == 640 && (g_pw320 & 8) && (p->Cout % 256) == 0 && p->Cout >= 1280;
+    if (p->C1 != 320 && !c640) return CCNET_OK;
+    const int GW = c640 ? 256 : 320;  // couts per block
     if (p->Cout % GW) return CCNET_OK;
-    const int G = p->Cout / GW;
-    if (G > 8 || (G > 1 && !(g_pw320 & 2))) return CCNET_OK;
+    const int G = (p->Cout + GW - 1) / GW;
+    if (G > 32 || (G > 1 && !(g_pw320 & 2))) return CCNET_OK;
     if ((p->act != 0 && p->act != 2) || (p->act == 2 && (p->res1 || !(g_pw320 & 4)))) return CCNET_OK;
     if (p->scale != 1.0f || p->rowvec || p->out2 || p->rowstat || p->stat_out || p->batch > 1) return CCNET_OK;
-    if (p->Hin != p->Hout || p->Win != p->Wout || M < 65536) return CCNET_OK;
+    if (p->Hin != p->Hout || p->Win != p->Wout || (long long)M * p->C1 < 65536ll * 320) return CCNET_OK;
     const long long xb = ((long long)M - 1) * p->ldx1 * 2 + p->C1 * 2;
     if (xb >= 0x7fffffffLL) return CCNET_OK;
     PwArgs a{};
     a.x = (const __bf16*)p->x1; a.w = (const __bf16*)p->w; a.bias = p->bias; a.res = (const __bf16*)p->res1; a.out = (__bf16*)p->out;
-    a.M = M; a.ldx = p->ldx1; a.ldw = p->ldw; a.ldres = p->ldres1; a.ldo = p->ldo; a.G = G;
+    a.M = M; a.ldx = p->ldx1; a.ldw = p->ldw; a.ldres = p->ldres1; a.ldo = p->ldo; a.G = G; a.Cout = p->Cout;
     a.chunks = (M + PW_ROWS - 1) / PW_ROWS;
     // row ranges: a multiple of 8 (one per XCD slot), ranges x G blocks fill one round of the chip
     // (one round of 8 floor(256 / 8 G) x G blocks measured 2-4 % faster than 256 or 128 ranges in three or four rounds: fewer
     // weight prologues)
-    const int ranges = 8 * (kNumCUs / (8 * G));
+    int ranges = 8 * (kNumCUs / (8 * G));
+    if (ranges * G < 208) ranges = 64;   // (many groups: several rounds of 64 ranges x G blocks)
     a.chunks_per_block = (a.chunks + ranges - 1) / ranges;
     a.x_bytes = (unsigned)xb;
     const int grid = ranges * G;
-    const int rc = p->act == 2 ? launch_pw<320, 10, 4, false, true>(a, grid, st)
+    const int rc = c640 ? (p->act == 2 ? launch_pw<640, 8, 3, false, true>(a, grid, st)
+                           : p->res1 ? launch_pw<640, 8, 3, true, false>(a, grid, st) : launch_pw<640, 8, 3, false, false>(a, grid, st))
+                 : p->act == 2 ? launch_pw<320, 10, 4, false, true>(a, grid, st)
                  : p->res1 ? launch_pw<320, 10, 4, true, false>(a, grid, st) : launch_pw<320, 10, 4, false, false>(a, grid, st);
     if (rc != CCNET_OK) return rc;
     *done = true;

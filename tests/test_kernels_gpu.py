@@ -81,10 +81,12 @@ def test_conv_gemm(cuda, case):
 @pytest.mark.parametrize("case", [(16, 64, True, 0, 320, 0, 320), (17, 64, False, 0, 320, 0, 320), (16, 64, True, 64, 320, 0, 320),
                                   (20, 60, True, 0, 320, 0, 320), (16, 64, False, 0, 960, 0, 320), (17, 64, True, 0, 960, 0, 320),
                                   (16, 64, False, 0, 2560, 2, 320), (18, 64, False, 64, 2560, 2, 320),
-                                  (17, 63, True, 0, 320, 0, 320), (17, 63, False, 0, 960, 0, 320), (17, 63, False, 0, 2560, 2, 320)])
+                                  (17, 63, True, 0, 320, 0, 320), (17, 63, False, 0, 960, 0, 320), (17, 63, False, 0, 2560, 2, 320),
+                                  (32, 32, False, 0, 1920, 0, 640), (33, 31, False, 64, 1920, 0, 640), (34, 32, False, 0, 5120, 2, 640),
+                                  (32, 32, True, 0, 1280, 0, 640)])
 def test_pointwise_streaming_kernel(cuda, case):
     """1x1 layers with 320 input channels at the 64x64 level (o-proj / proj_in / proj_out / to_q, qkv, ff.linear1 +
-    GEGLU) run on the weight-stationary streaming kernel (weights in registers, pixel rows through an LDS ring): bit-identical
+    GEGLU) and the wide ones with 640 at the 32x32 level (qkv, ff.linear1 + GEGLU) run on the weight-stationary streaming kernel (weights in registers, pixel rows through an LDS ring): bit-identical
     to the tiled kernel (ccnet_set_option(8, 0)), within tolerance of the fp32 product.  Cases: with / without residual, row
     counts that are not a whole number of chunks per block or of 32-row chunks (67473 rows), inputs that are column views of wider rows, several cout groups,
     GEGLU."""
@@ -107,7 +109,7 @@ def test_pointwise_streaming_kernel(cuda, case):
     try:
         tiled = ops.conv(x, wk, bk, Cout, R=1, pad=0, res1=res, act=act)
     finally:
-        L.load().ccnet_set_option(8, 7)
+        L.load().ccnet_set_option(8, 15)
     assert torch.equal(out.t, tiled.t), f"streaming vs tiled kernel differ: max {(out.t.float() - tiled.t.float()).abs().max().item()}"
     ref = x.t.float() @ w.float().T.to(cuda) + b.to(cuda)
     if act == 2:
