@@ -715,11 +715,18 @@ struct PwArgs {
     int G;  // cout groups (Cout <= 32 WAVES G): G blocks walk the same row range, one group each
     int Cout;  // (GEGLU: rows of w; the last group may be partial: its waves beyond Cout only stage rows and meet the barriers)
     unsigned x_bytes;
+    const float* colsum; float ln_eps;  // LNF
 };
 
-template <int C, int WAVES, int NSTG, bool RES, bool GEGLU>
+// LNF: the LayerNorm in front of the layer, folded (ops.fold_layernorm: w = gamma o W, bias = bias + W beta, colsum = row sums
+// of w) with the row statistics taken HERE, from fragments the waves read anyway: wave w sums (shifted by the row's first
+// element) the two 16-channel k-steps 2 w, 2 w + 1 of the chunk's 32 rows into an LDS table, no cross-lane reduction; one
+// iteration later (the barrier in between publishes the table) every lane adds the 2 x WAVES partials of its pixel and turns
+// the raw products of that chunk into rstd (acc - mean colsum) + bias.  The normalised rows never exist in HBM.
+template <int C, int WAVES, int NSTG, bool RES, bool GEGLU, bool LNF = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a) {
     static_assert(!(RES && GEGLU), "GEGLU layers carry no residual");
+    static_assert(!LNF || (!RES && C / 16 == 2 * WAVES), "LayerNorm-fed layers carry no residual; two k-steps per wave");
     static_assert(C == 320 || C == 640, "row swizzle below: 40 or 80 16-byte units per row");
     constexpr int ROWB = C * 2, CHUNKB = PW_ROWS * ROWB, UPR = C / 8;      // bytes per row / chunk, 16-byte units per row
     constexpr int PIECES = CHUNKB / 1024, PPW = PIECES / WAVES;             // 1-KiB DMA pieces per chunk / per wave
@@ -735,6 +742,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
     if (c_lo >= c_hi) return;  // (whole block: no barrier is pending)
     const int n0 = GW * grp;   // first cout of the block's group
     const bool wact = n0 + 32 * wave < a.Cout;  // wave-uniform
+    // LNF tables behind the ring: colsum[GW] | bias[GW] | partial sums [2][WAVES][64] (s, q) | first elements [2][32]
+    float* cbs = (float*)(smem + NSTG * CHUNKB);
+    float* ptab = cbs + 2 * GW;
+    float* x0tab = ptab + 2 * WAVES * 64 * 2;
+    if constexpr (LNF) {
+        for (int t = tid; t < GW; t += 64 * WAVES) {
+            cbs[t] = a.colsum[n0 + t];
+            cbs[GW + t] = a.bias ? a.bias[n0 + t] : 0.f;
+        }
+    }
 
     // the wave's weight fragments: lane holds W[n0 + 32 wave + l31][16 ks + 8 hh .. + 7]
     bf16x8 wf[KS];
@@ -747,7 +764,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
     f32x16 bq;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 t = (a.bias && wact) ? *(const f32x4*)(a.bias + n0 + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 t = (a.bias && wact && !LNF) ? *(const f32x4*)(a.bias + n0 + 32 * wave + 8 * q + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) bq[4 * q + e] = t[e];
     }
@@ -796,23 +813,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
 #pragma unroll
     for (int i = 0; i < NSTG - 1; ++i) issue_chunk(c_lo + i);
     // all landed: the counted wait of the loop assumes NSTG - 2 whole iterations of younger operations behind the DMA it waits for
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the LNF tables written above)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    for (int c = c_lo; c < c_hi; ++c) {
-        // memory operations of an iteration, in issue order: residual rows of chunk c + 1 (RES), DMA of chunk c + NSTG - 1, stores
-        // of chunk c.  The residual is issued first so that waiting for it (next iteration) never waits for the newest DMAs.
-        u32x4 rn[2];
-        if constexpr (RES) res_load(c + 1, rn);
-        issue_chunk(c + NSTG - 1);
-        const char* xb = smem + (c % NSTG) * CHUNKB + xrow;
-        f32x16 acc = bq;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 xf = *(const bf16x8*)(xb + (((2 * ks) << 4) ^ xsw));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
-        }
+    // writes the 32 x 32 outputs of one chunk from their accumulators (values after bias / LayerNorm fold)
+    auto store_chunk = [&](const f32x16& acc, int c) {
         const long long m = (long long)c * PW_ROWS + l31;
         __bf16* orow = a.out + m * a.ldo + col0;
         if constexpr (GEGLU) {
@@ -831,32 +837,104 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
             swap32(d0, d2);
             swap32(d1, d3);
             if (wact && m < a.M) *(u32x4*)orow = u32x4{d0, d1, d2, d3};
-        } else
+        } else {
 #pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2) {
-            float w8[8];
+            for (int p2 = 0; p2 < 2; ++p2) {
+                float w8[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned lo = __float_as_uint(acc[8 * p2 + e]), hi = __float_as_uint(acc[8 * p2 + 4 + e]);
-                swap32(lo, hi);
-                w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
+                for (int e = 0; e < 4; ++e) {
+                    unsigned lo = __float_as_uint(acc[8 * p2 + e]), hi = __float_as_uint(acc[8 * p2 + 4 + e]);
+                    swap32(lo, hi);
+                    w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
+                }
+                if constexpr (RES) {
+                    float r8[8];
+                    unpack8(rc[p2], r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w8[e] += r8[e];
+                }
+                if (wact && m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
             }
-            if constexpr (RES) {
-                float r8[8];
-                unpack8(rc[p2], r8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) w8[e] += r8[e];
-            }
-            if (wact && m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
         }
-        if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
-        // chunk c + 1 must have landed.  Younger than its DMAs (issued NSTG - 2 iterations ago): that iteration's stores and
-        // NSTG - 2 whole iterations of (residual loads +) DMAs + stores
+    };
+    // LNF: raw products of chunk c -> rstd (acc - mean colsum) + bias, then the stores
+    auto finish_ln = [&](f32x16 acc, int c) {
+        const float* pt = ptab + (c & 1) * (WAVES * 64 * 2);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const f32x2 p0 = *(const f32x2*)(pt + (w * 64 + l31) * 2), p1 = *(const f32x2*)(pt + (w * 64 + 32 + l31) * 2);
+            sm += p0[0] + p1[0];
+            sq += p0[1] + p1[1];
+        }
+        sm *= 1.0f / C;
+        sq *= 1.0f / C;
+        const float mean = x0tab[(c & 1) * PW_ROWS + l31] + sm;
+        const float rstd = rsqrtf(fmaxf(sq - sm * sm, 0.f) + a.ln_eps);
+        const float nmr = -mean * rstd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 cs = *(const f32x4*)(cbs + 32 * wave + 8 * q + 4 * hh);
+            const f32x4 bb = *(const f32x4*)(cbs + GW + 32 * wave + 8 * q + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * q + e] = fmaf(rstd, acc[4 * q + e], fmaf(nmr, cs[e], bb[e]));
+        }
+        store_chunk(acc, c);
+    };
+
+    f32x16 acc_prev = {};
+    for (int c = c_lo; c < c_hi; ++c) {
+        // memory operations of an iteration, in issue order: residual rows of chunk c + 1 (RES), DMA of chunk c + NSTG - 1, stores
+        // (LNF: of chunk c - 1).  The residual is issued first so that waiting for it (next iteration) never waits for the newest DMAs.
+        u32x4 rn[2];
+        if constexpr (RES) res_load(c + 1, rn);
+        issue_chunk(c + NSTG - 1);
+        const char* xb = smem + (c % NSTG) * CHUNKB + xrow;
+        if constexpr (LNF) {
+            // the previous chunk first: its accumulators die before this chunk's are born (168 registers at 10 waves)
+            if (c > c_lo) finish_ln(acc_prev, c - 1);
+            // shift = the row's first element (unit 0 sits at position swz(row)); this wave's share: k-steps 2 wave, 2 wave + 1
+            const float x0 = bf16_bits_to_f32(*(const unsigned short*)(xb + (swz(l31) << 4)));
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float f[8];
+                unpack8(*(const u32x4*)(xb + (((2 * (2 * wave + i)) << 4) ^ xsw)), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = f[e] - x0;
+                    sm += d;
+                    sq = fmaf(d, d, sq);
+                }
+            }
+            *(f32x2*)(ptab + ((c & 1) * WAVES * 64 + wave * 64 + lane) * 2) = f32x2{sm, sq};
+            if (wave == 0 && hh == 0) x0tab[(c & 1) * PW_ROWS + l31] = x0;
+        }
+        f32x16 acc = bq;
+        if constexpr (LNF) acc = f32x16{};  // (the bias joins after the normalisation)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 xf = *(const bf16x8*)(xb + (((2 * ks) << 4) ^ xsw));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+        }
         constexpr int ST = GEGLU ? 1 : 2, PER = (RES ? 2 : 0) + PPW + ST;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST + (NSTG - 2) * PER) : "memory");
+        if constexpr (LNF) {
+            acc_prev = acc;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this chunk's partial sums are in LDS before the barrier
+            // (the first iterations carry fewer stores than the count below assumes)
+            if (c < c_lo + NSTG - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST + (NSTG - 2) * PER) : "memory");
+        } else {
+            store_chunk(acc, c);
+            if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
+            // chunk c + 1 must have landed.  Younger than its DMAs (issued NSTG - 2 iterations ago): that iteration's stores and
+            // NSTG - 2 whole iterations of (residual loads +) DMAs + stores
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST + (NSTG - 2) * PER) : "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    if constexpr (LNF) finish_ln(acc_prev, c_hi - 1);
 }
 
 // ---------------------------------------------------------------- profiling hooks
@@ -877,21 +955,22 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
-int g_pw320 = 15;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: several cout groups too;
-                   // bit 2: GEGLU too; bit 3: 640 input channels too (8 waves x 160 weight registers, 256 couts per block)
+int g_pw320 = 31;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: several cout groups too;
+                   // bit 2: GEGLU too; bit 3: 640 input channels too (8 waves x 160 weight registers, 256 couts per block);
+                   // bit 4: LayerNorm statistics in the kernel (colsum without rowstat)
 
 // CCNET_OK + *done = true if the problem is one of these layers and was launched here
-template <int C, int WAVES, int NSTG, bool RES, bool GEGLU>
+template <int C, int WAVES, int NSTG, bool RES, bool GEGLU, bool LNF = false>
 int launch_pw(const PwArgs& a, int grid, hipStream_t st) {
-    constexpr int LDS = NSTG * PW_ROWS * C * 2;
+    constexpr int LDS = NSTG * PW_ROWS * C * 2 + (LNF ? (2 * 32 * WAVES + 2 * WAVES * 64 * 2 + 2 * PW_ROWS) * 4 : 0);
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)pw_stream_kernel<C, WAVES, NSTG, RES, GEGLU>,
+        if (hipFuncSetAttribute((const void*)pw_stream_kernel<C, WAVES, NSTG, RES, GEGLU, LNF>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((pw_stream_kernel<C, WAVES, NSTG, RES, GEGLU>), dim3(grid), dim3(64 * WAVES), LDS, st, a);
+    hipLaunchKernelGGL((pw_stream_kernel<C, WAVES, NSTG, RES, GEGLU, LNF>), dim3(grid), dim3(64 * WAVES), LDS, st, a);
     return hipGetLastError() == hipSuccess ? CCNET_OK : CCNET_ELAUNCH;
 }
 
@@ -911,6 +990,8 @@ int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     if (G > 32 || (G > 1 && !(g_pw320 & 2))) return CCNET_OK;
     if ((p->act != 0 && p->act != 2) || (p->act == 2 && (p->res1 || !(g_pw320 & 4)))) return CCNET_OK;
     if (p->scale != 1.0f || p->rowvec || p->out2 || p->rowstat || p->stat_out || p->batch > 1) return CCNET_OK;
+    const bool lnf = p->colsum != nullptr;  // (without rowstat: the row statistics are taken in the kernel)
+    if (lnf && (p->res1 || p->act != 0 || c640 || !(g_pw320 & 16))) return CCNET_OK;
     if (p->Hin != p->Hout || p->Win != p->Wout || (long long)M * p->C1 < 65536ll * 320) return CCNET_OK;
     const long long xb = ((long long)M - 1) * p->ldx1 * 2 + p->C1 * 2;
     if (xb >= 0x7fffffffLL) return CCNET_OK;
@@ -926,7 +1007,9 @@ int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     a.chunks_per_block = (a.chunks + ranges - 1) / ranges;
     a.x_bytes = (unsigned)xb;
     const int grid = ranges * G;
-    const int rc = c640 ? (p->act == 2 ? launch_pw<640, 8, 3, false, true>(a, grid, st)
+    a.colsum = p->colsum; a.ln_eps = p->ln_eps;
+    const int rc = lnf ? launch_pw<320, 10, 4, false, false, true>(a, grid, st)
+                 : c640 ? (p->act == 2 ? launch_pw<640, 8, 3, false, true>(a, grid, st)
                            : p->res1 ? launch_pw<640, 8, 3, true, false>(a, grid, st) : launch_pw<640, 8, 3, false, false>(a, grid, st))
                  : p->act == 2 ? launch_pw<320, 10, 4, false, true>(a, grid, st)
                  : p->res1 ? launch_pw<320, 10, 4, true, false>(a, grid, st) : launch_pw<320, 10, 4, false, false>(a, grid, st);
@@ -1218,8 +1301,8 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     if (p->act < 0 || p->act > 2) return CCNET_EINVAL;
     if (p->act == 2 && (p->Cout % 64)) return CCNET_EINVAL;
     if (p->act == 2 && p->rowvec) return CCNET_EUNSUP;  // GEGLU: interleaved 32-row a / gate blocks
-    if ((p->rowstat != nullptr) != (p->colsum != nullptr)) return CCNET_EINVAL;
-    if (p->rowstat && (p->R != 1 || p->C2 != 0 || p->rowvec || batch > 1 || p->stride != 1 || p->ups != 1)) return CCNET_EUNSUP;
+    if (p->rowstat && !p->colsum) return CCNET_EINVAL;   // (colsum alone: statistics in the kernel, streaming instance only)
+    if (p->colsum && (p->R != 1 || p->C2 != 0 || p->rowvec || batch > 1 || p->stride != 1 || p->ups != 1)) return CCNET_EUNSUP;
     if (p->rowstat && p->rowstat_parts != 0 && p->rowstat_parts != 2 && p->rowstat_parts != 4 && p->rowstat_parts != 8) return CCNET_EUNSUP;
     if (p->rowstat && p->rowstat_parts > 0 && (p->C1 % p->rowstat_parts)) return CCNET_EINVAL;
     if (p->stat_out && (p->act == 2 || batch > 1)) return CCNET_EUNSUP;
@@ -1277,6 +1360,10 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
         if (rc != CCNET_OK || done) {
             if (rec) (void)hipEventRecord(rec->e1, st);
             return rc;
+        }
+        if (p->colsum && !p->rowstat) {  // only the streaming instance takes the row statistics itself
+            if (rec) --g_prof_used;
+            return CCNET_EUNSUP;
         }
     }
     const bool geglu = p->act == 2;

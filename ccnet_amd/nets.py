@@ -37,6 +37,10 @@ BF16 = torch.bfloat16
 # without -- the write it saves is served from the Infinity Cache anyway and the GEMM's accumulator start gets heavier -- so
 # the separate LayerNorm kernel stays the default and the fold is an option (parity-tested either way).
 LN_FOLD = os.environ.get("CCNET_LN_FOLD", "0") == "1"
+# CCNET_LN_INLINE=1 (default): norm1 -> qkv and norm2 -> attn2.to_q of the 320-channel level run as ONE launch each, the
+# streaming pointwise kernel taking the row statistics from the rows it stages anyway (ops.ln_inline_ok); the normalised
+# rows are never written.  Other levels / small batches keep the LayerNorm kernel.
+LN_INLINE = os.environ.get("CCNET_LN_INLINE", "1") == "1"
 # Head dim 64: softmax scale * log2(e) folded into the packed to_q weights (one bf16 rounding of the scaled fp32 weight), the
 # attention kernel then runs its prescaled instance (no multiply in front of the exponential).  CCNET_ATTN_PRESCALE=0: A/B.
 ATTN_PRESCALE = os.environ.get("CCNET_ATTN_PRESCALE", "1") == "1"
@@ -267,7 +271,15 @@ class _Trunk(nn.Module):
                 f_q2 = dv(ops.fold_layernorm(b.attn2.to_q.weight, None, b.norm2.weight, b.norm2.bias))
                 w1, b1, c1 = ops.fold_layernorm(b.ff.linear1.weight, b.ff.linear1.bias, b.norm3.weight, b.norm3.bias)
                 f_ff1 = dv((ops.geglu_interleave(w1), ops.geglu_interleave(b1), ops.geglu_interleave(c1)))
+            i_qkv = i_q2 = None
+            if LN_INLINE and not LN_FOLD and inner == 320:
+                dv = lambda t: tuple(x.to(dev) for x in t)
+                qs = qscale if ATTN_PRESCALE and a.head_ch == 64 else 1.0
+                i_qkv = dv(ops.fold_layernorm(torch.cat([b.attn1.to_q.weight.detach().float() * qs, b.attn1.to_k.weight.detach().float(),
+                                                         b.attn1.to_v.weight.detach().float()], 0), None, b.norm1.weight, b.norm1.bias))
+                i_q2 = dv(ops.fold_layernorm(b.attn2.to_q.weight.detach().float() * qs, None, b.norm2.weight, b.norm2.bias))
             return {
+                "qkv1i": i_qkv, "q2i": i_q2,
                 "qkv1f": f_qkv, "q2f": f_q2, "ff1f": f_ff1,
                 "norm": (f32(a.norm.weight), f32(a.norm.bias)), "pin": pconv(a.proj_in.conv),
                 "pout": pconv(a.proj_out.conv), "heads": a.heads, "head_ch": a.head_ch, "inner": inner,
@@ -456,10 +468,19 @@ class _Trunk(nn.Module):
             gl = ops.linear(t, w, b, 8 * inner, inner, act=2, rowstat=stats_of(t, st), colsum=cs)
         else:
             t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
-            qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1s"] if pre else p["qkv1"], None, 3 * inner, inner)
+            inl = p["qkv1i"] is not None and ops.ln_inline_ok(t.shape[0], inner, inner)
+            if inl:
+                w, b, cs = p["qkv1i"]
+                qkv = ops.linear(t, w, b, 3 * inner, inner, colsum=cs)
+            else:
+                qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1s"] if pre else p["qkv1"], None, 3 * inner, inner)
             o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
             t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
-            q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
+            if inl:
+                w, b, cs = p["q2i"]
+                q = ops.linear(t, w, b, inner, inner, colsum=cs)
+            else:
+                q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
             o = attend(q, kv[:, :inner], kv[:, inner:], S)
             t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
             gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)

@@ -61,6 +61,7 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
     """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given.
     rowstat / colsum: LayerNorm folded into the layer (include/ccnet_hip.h: x holds the un-normalised rows, w and bias the
     folded parameters of `fold_layernorm`, rowstat = row_stats(x) [rows, 2], or a producer's partials [rows, P, 2]).
+    colsum alone: the kernel takes the statistics itself (only where `ln_inline_ok`).
     emit_stats: returns (Act, stats) with stats = the per-row (mean, M2) partials [rows, P, 2] of the output, taken in the
     epilogue, or None when the layer's plan cannot emit them (the caller then runs row_stats on the output)."""
     lib = _l.load()
@@ -92,8 +93,13 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
     p.ldres2 = res2.ld if res2 is not None else 0
     p.ld_rowvec = rowvec.stride(0) if rowvec is not None else 0
     p.act = act; p.scale = scale; p.batch = 1
-    if (rowstat is None) != (colsum is None):
-        raise _l.CcnetError("rowstat and colsum come together")
+    if rowstat is not None and colsum is None:
+        raise _l.CcnetError("rowstat needs colsum")
+    if rowstat is None and colsum is not None:
+        # LayerNorm statistics taken inside the streaming pointwise kernel (ln_inline_ok says which layers it takes)
+        if colsum.dtype != torch.float32 or colsum.numel() < Cout:
+            raise _l.CcnetError("colsum must be fp32 [>= Cout]")
+        p.colsum = colsum.data_ptr(); p.ln_eps = ln_eps
     if rowstat is not None:
         parts = rowstat.shape[1] if rowstat.dim() == 3 else 0
         if rowstat.dtype != torch.float32 or rowstat.numel() != 2 * out.rows * max(parts, 1) or colsum.dtype != torch.float32 \
@@ -157,6 +163,13 @@ def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], Cou
     r = conv(xa, w, bias, Cout, R=1, pad=0, res1=ra, scale=scale, act=act, rowstat=rowstat, colsum=colsum, ln_eps=ln_eps,
              emit_stats=emit_stats)
     return (r[0].t, r[1]) if emit_stats else r.t
+
+
+def ln_inline_ok(rows: int, Cin: int, Cout: int) -> bool:
+    """Whether linear(x, w, b, Cout, Cin, colsum=...) WITHOUT rowstat is served: the layers that the weight-stationary streaming
+    kernel takes with the LayerNorm statistics computed in the kernel (gemm_conv.hip try_pw320: 320 input channels, whole
+    320-cout groups, enough rows to fill the chip); any other shape returns CCNET_EUNSUP from the library."""
+    return Cin == 320 and Cout % 320 == 0 and Cout // 320 <= 32 and rows >= 65536
 
 
 def row_stats(x2d: torch.Tensor, Cc: int, eps: float = 1e-5) -> torch.Tensor:

@@ -81,7 +81,10 @@ typedef struct ccnet_conv_params {
      * weights), rowstat[m] = {mean, rstd} of row m (ccnet_row_stats_bf16).  Then
      *   out[m][n] = act( rstd[m] * (sum_k x1[m][k] w[n][k] - mean[m] * colsum[n]) + bias[n] ) ...
      * = act(LayerNorm(x1)[m] . W[n] + bias[n]) without the normalised tensor ever existing in HBM.  Both NULL: plain GEMM.
-     * Needs R = 1, one source, no rowvec, batch 1; never runs split along K. */
+     * Needs R = 1, one source, no rowvec, batch 1; never runs split along K.
+     * colsum WITHOUT rowstat (ln_eps set): the kernel takes mean / rstd of every row itself, from the rows it stages.  Only the
+     * weight-stationary streaming kernel does that (C1 = 320, Cout a multiple of 320 up to 10240, M >= 65536, act = 0, no
+     * residual, no second output); any other problem returns CCNET_EUNSUP and the caller runs ccnet_layernorm_bf16. */
     const float* rowstat; /* fp32 [M][2] or NULL */
     const float* colsum;  /* fp32 [Cout] or NULL */
     /* rowstat_parts > 0: rowstat is instead fp32 [M][rowstat_parts][2] = (mean, M2) of that many equal column spans of

@@ -109,7 +109,7 @@ def test_pointwise_streaming_kernel(cuda, case):
     try:
         tiled = ops.conv(x, wk, bk, Cout, R=1, pad=0, res1=res, act=act)
     finally:
-        L.load().ccnet_set_option(8, 15)
+        L.load().ccnet_set_option(8, 31)
     assert torch.equal(out.t, tiled.t), f"streaming vs tiled kernel differ: max {(out.t.float() - tiled.t.float()).abs().max().item()}"
     ref = x.t.float() @ w.float().T.to(cuda) + b.to(cuda)
     if act == 2:
@@ -117,6 +117,38 @@ def test_pointwise_streaming_kernel(cuda, case):
     if with_res:
         ref = ref + res.t.float()
     _close(out.t.float(), ref, atol=3e-2, what=f"pointwise streaming {case}")
+
+
+@pytest.mark.parametrize("case", [(65536, 0, 320), (65536, 64, 960), (67473, 0, 960), (131072, 0, 320)])
+def test_pointwise_streaming_layernorm_inline(cuda, case):
+    """LayerNorm -> Linear with the row statistics taken INSIDE the streaming kernel (colsum without rowstat: norm1 -> qkv and
+    norm2 -> attn2.to_q of the 320-channel level): against fp32 LayerNorm + Linear, and against the form that feeds the same
+    folded GEMM with ccnet_row_stats_bf16.  Rows include large offsets (the in-kernel sums are shifted by the row's first
+    element), a constant row (variance 0) and a ragged row count; a shape the streaming kernel does not take is refused."""
+    ops = _ops()
+    from ccnet_amd import lib as L
+    M, extra, Cout = case
+    g = torch.Generator().manual_seed(91)
+    xs = torch.randn(M, 320 + extra, generator=g)
+    xs[1::7] += 30.0   # offset rows: E[x^2] - E[x]^2 around 900 would lose the variance of 1 without the shift
+    xs[5::11] *= 4.0
+    xs[3] = 2.5        # constant row
+    wide = xs.to(torch.bfloat16).to(cuda)
+    x = wide[:, extra:]
+    gamma, beta = 1 + 0.2 * torch.randn(320, generator=g), 0.3 * torch.randn(320, generator=g)
+    w = torch.randn(Cout, 320, generator=g) / math.sqrt(320)
+    b = torch.randn(Cout, generator=g)
+    wf, bf, cs = (t.to(cuda) for t in ops.fold_layernorm(w, b, gamma, beta))
+    assert ops.ln_inline_ok(M, 320, Cout)
+    out = ops.linear(x, wf, bf, Cout, 320, colsum=cs)
+    fed = ops.linear(x, wf, bf, Cout, 320, rowstat=ops.row_stats(x, 320), colsum=cs)
+    ref = F.layer_norm(x.float(), (320,), gamma.to(cuda), beta.to(cuda)) @ w.to(cuda).T + b.to(cuda)
+    _close(out.float(), ref, atol=6e-2, what=f"layernorm in the streaming kernel {case}")
+    d = (out.float() - fed.float()).abs()
+    assert d.max().item() <= 6e-2 and (d > 0).float().mean().item() < 0.05, f"vs row_stats-fed GEMM: max {d.max().item()}"
+    assert not ops.ln_inline_ok(4096, 320, Cout)
+    with pytest.raises(L.CcnetError):
+        ops.linear(x[:4096], wf, bf, Cout, 320, colsum=cs)
 
 
 def test_conv_epilogue_full(cuda):
