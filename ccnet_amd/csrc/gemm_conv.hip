@@ -709,6 +709,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a) {
 // HBM once and from that XCD's L2 for the other G - 1 groups.
 // GEGLU: the wave's 32 weight rows are 8-row value / gate blocks (ops.geglu_interleave); it writes 16 outputs per pixel.
 constexpr int PW_ROWS = 32;
+#ifndef PW_DIAG
+#define PW_DIAG 0  // timing experiments (tools/pw_diag.sh): bit 0 no output stores, bit 1 no MFMAs, bit 2 the row DMAs fetch nothing
+#endif
 struct PwArgs {
     const __bf16* x; const __bf16* w; const float* bias; const __bf16* res; __bf16* out;
     int M, ldx, ldw, ldres, ldo, chunks, chunks_per_block;
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
         const unsigned long long off = (unsigned long long)c * chunk_b;
         const bool ok = c < c_hi && off < 0x7fffffffull;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) buf_dma16(rx, base + i * 1024, ok ? dvo[i] + (unsigned)off : OOB);
+        for (int i = 0; i < PPW; ++i) buf_dma16(rx, base + i * 1024, (ok && !(PW_DIAG & 4)) ? dvo[i] + (unsigned)off : OOB);
     };
     // fragment read: row l31, unit (2 ks + hh) ^ swz(l31) = (2 ks) ^ (hh ^ swz(l31)): a lane constant XOR a literal
     const int xrow = l31 * ROWB, xsw = (hh ^ swz(l31)) << 4;
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
             unsigned d2 = pack_bf16x2(r8[4], r8[5]), d3 = pack_bf16x2(r8[6], r8[7]);
             swap32(d0, d2);
             swap32(d1, d3);
-            if (wact && m < a.M) *(u32x4*)orow = u32x4{d0, d1, d2, d3};
+            if (wact && m < ((PW_DIAG & 1) ? -a.M : a.M)) *(u32x4*)orow = u32x4{d0, d1, d2, d3};
         } else {
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w8[e] += r8[e];
                 }
-                if (wact && m < a.M) *(u32x4*)(orow + 16 * p2) = pack8(w8);
+                if (wact && m < ((PW_DIAG & 1) ? -a.M : a.M)) *(u32x4*)(orow + 16 * p2) = pack8(w8);
             }
         }
     };
@@ -915,9 +918,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 xf = *(const bf16x8*)(xb + (((2 * ks) << 4) ^ xsw));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+            if constexpr (PW_DIAG & 2) acc[ks & 15] += __builtin_bit_cast(f32x4, xf)[ks & 3];
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
         }
-        constexpr int ST = GEGLU ? 1 : 2, PER = (RES ? 2 : 0) + PPW + ST;
+        constexpr int ST = (PW_DIAG & 1) ? 0 : GEGLU ? 1 : 2, PER = (RES ? 2 : 0) + PPW + ST;
         if constexpr (LNF) {
             acc_prev = acc;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this chunk's partial sums are in LDS before the barrier
