@@ -24,6 +24,9 @@
 #include <mutex>
 #include <vector>
 
+#ifndef CONV_DIAG
+#define CONV_DIAG 0  // timing experiment: bit 0 = the plain epilogue of the tiled kernel loads no residual and stores nothing
+#endif
 namespace {
 
 #ifdef CCNET_STAMP
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int m = cm0 + wm * 32 * TJ + j * 32 + l31;
-            const bool mok = m < a.M;
+            const bool mok = m < ((CONV_DIAG & 1) ? -a.M : a.M);
             __bf16* orow = outp + (long long)m * a.ldo;
             __bf16* orow2 = a.out2 + (long long)m * a.ldo2;
             const __bf16* r1row = a.res1 + (long long)m * a.ldres1;
@@ -933,7 +936,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
             if constexpr (RES) { rc[0] = rn[0]; rc[1] = rn[1]; }
             // chunk c + 1 must have landed.  Younger than its DMAs (issued NSTG - 2 iterations ago): that iteration's stores and
             // NSTG - 2 whole iterations of (residual loads +) DMAs + stores
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST + (NSTG - 2) * PER) : "memory");
+            // (a wave beyond Cout in a partial last group stores nothing: its count is the DMAs alone; no such group with RES)
+            if (wact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST + (NSTG - 2) * PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * PPW) : "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -986,10 +991,10 @@ int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     // Pays where many cout groups share the rows (qkv 1920: 101-109 -> 83 us, ff.linear1 + GEGLU 5120: 256-273 -> 226 us); for
     // the 640-cout layers it does not (proj 44 -> 47 us, o-proj + res 43 -> 42: 2.5 groups padded to 3, 32768 rows per 328 KB
     // weight prologue), nor did a four-wave form with 128 couts per block (one wave per SIMD): those stay on the tiled kernel.
-    const bool c640 = p->C1 == 640 && (g_pw320 & 8) && (p->Cout % 256) == 0 && p->Cout >= 1280;
+    const bool c640 = p->C1 == 640 && (g_pw320 & 8) && p->Cout >= 1280 && ((p->Cout % 256) == 0 || ((p->Cout % 32) == 0 && !p->res1));
     if (p->C1 != 320 && !c640) return CCNET_OK;
     const int GW = c640 ? 256 : 320;  // couts per block
-    if (p->Cout % GW) return CCNET_OK;
+    if ((p->Cout % GW) && !c640) return CCNET_OK;  // (a partial last group: 640-channel instance without residual only)
     const int G = (p->Cout + GW - 1) / GW;
     if (G > 32 || (G > 1 && !(g_pw320 & 2))) return CCNET_OK;
     if ((p->act != 0 && p->act != 2) || (p->act == 2 && (p->res1 || !(g_pw320 & 4)))) return CCNET_OK;

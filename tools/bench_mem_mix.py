@@ -27,4 +27,4 @@ for name, f, mb in [("fill 252 MB (write only)", lambda: y3.fill_(1.0), 3 * MB),
                     ("cat 84 -> 252 MB", lambda: torch.cat((x, x, x), 1, out=y3), 4 * MB),
                     ("sum 84 MB (read only)", lambda: x.sum(), MB)]:
     t = timeit(f)
-    print(f"{name}: {t:.1f} us, {mb / t * 1e-6 * 1e6 / 1e6:.2f} TB/s", flush=True)
+    print(f"{name}: {t:.1f} us, {mb / t:.2f} TB/s", flush=True)
