@@ -105,18 +105,22 @@ def conv_algorithmic_bytes(M, Cout, K, R, flags):
 
 
 def hbm_traffic_per_launch():
-    """HBM bytes per conv_gemm launch from the committed PMC passes (profiles/*_hbm_traffic.csv, newest file):
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all instantiations -- bench.py cannot collect counters
+    """HBM bytes per ccnet_conv_gemm_bf16 launch from the committed PMC passes (profiles/*_hbm_traffic.csv, newest file):
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all instantiations of conv_gemm_kernel and pw_stream_kernel -- bench.py cannot collect counters
     itself, so this is the figure of the rocprofv3 --pmc runs of this same command."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
     if not files:
         return None
-    for line in open(files[-1]):
-        if line.startswith('"conv_gemm_kernel (all instantiations)"'):
-            f = line.rstrip().split(",")
-            return {"bytes_per_launch": round(float(f[-1]) * 2 ** 20), "source": os.path.relpath(files[-1], ROOT)}
-    return None
+    # every launch that ccnet_conv_gemm_bf16 makes: the tiled kernel's instantiations and the streaming instance
+    import csv
+    n = f = w = 0.0
+    for row in csv.reader(l for l in open(files[-1]) if not l.startswith("#")):
+        if len(row) == 5 and (row[0].startswith("conv_gemm_kernel<") or row[0].startswith("pw_stream_kernel<")):
+            n += float(row[1]); f += float(row[2]); w += float(row[3])
+    if not n:
+        return None
+    return {"bytes_per_launch": round((2 * f + w) * 1024 / n), "source": os.path.relpath(files[-1], ROOT)}
 
 
 def launch_ranks(n: int) -> int:
