@@ -119,12 +119,13 @@ def test_pointwise_streaming_kernel(cuda, case):
     _close(out.t.float(), ref, atol=3e-2, what=f"pointwise streaming {case}")
 
 
-@pytest.mark.parametrize("case", [(65536, 0, 320), (65536, 64, 960), (67473, 0, 960), (131072, 0, 320)])
+@pytest.mark.parametrize("case", [(65536, 0, 320), (65536, 64, 960), (67473, 0, 960), (131072, 0, 320), (65690, 0, 320)])
 def test_pointwise_streaming_layernorm_inline(cuda, case):
     """LayerNorm -> Linear with the row statistics taken INSIDE the streaming kernel (colsum without rowstat: norm1 -> qkv and
     norm2 -> attn2.to_q of the 320-channel level): against fp32 LayerNorm + Linear, and against the form that feeds the same
     folded GEMM with ccnet_row_stats_bf16.  Rows include large offsets (the in-kernel sums are shifted by the row's first
-    element), a constant row (variance 0) and a ragged row count; a shape the streaming kernel does not take is refused."""
+    element), a constant row (variance 0) and ragged row counts (65690 rows: the last block's range is one partial chunk); a shape
+    the streaming kernel does not take is refused."""
     ops = _ops()
     from ccnet_amd import lib as L
     M, extra, Cout = case
