@@ -110,7 +110,9 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         vlane[d] = (4 * hh + tq) * 128 + ((chunk ^ (((tq >> 1) & 1) << 2)) << 4) + (tp & 1) * 8;
     }
 
-    const int ntiles = (a.Skv + KV_TILE - 1) / KV_TILE;
+    // CAUSAL: the 128 queries of the block see keys < (blockIdx.x + 1) * 128 at most: key tiles entirely above the diagonal are not walked
+    const int kv_end = CAUSAL ? min(a.Skv, ((int)blockIdx.x + 1) * 128) : a.Skv;
+    const int ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
     issue_loads(0);
     store_stage(0);
     __syncthreads();
@@ -202,12 +204,12 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_kernel(const AttnArgs 
         __syncthreads();
     };
     // only the last tile can hold keys beyond Skv: the masking code exists in that instance alone
-    const bool ragged = (a.Skv % KV_TILE) != 0;
+    const bool ragged = (kv_end % KV_TILE) != 0;
     using two = std::integral_constant<int, 2>;
     using one = std::integral_constant<int, 1>;
     for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::false_type{}, two{});
     // a tail of <= 32 keys (77 prompt tokens = 64 + 13) skips its empty second block: scores, softmax and P.V alike
-    if (ragged && a.Skv - (ntiles - 1) * KV_TILE <= 32) tile_body(ntiles - 1, std::true_type{}, one{});
+    if (ragged && kv_end - (ntiles - 1) * KV_TILE <= 32) tile_body(ntiles - 1, std::true_type{}, one{});
     else if (ragged) tile_body(ntiles - 1, std::true_type{}, two{});
     else tile_body(ntiles - 1, std::false_type{}, two{});
 

@@ -827,7 +827,7 @@ def test_conv_dispatch_sweep(cuda):
 
 
 # ------------------------------------------------------------------ text tower kernels
-@pytest.mark.parametrize("case", [(2, 2, 77), (1, 3, 200), (3, 1, 128), (2, 2, 5)])
+@pytest.mark.parametrize("case", [(2, 2, 77), (1, 3, 200), (3, 1, 128), (2, 2, 5), (1, 2, 300)])
 def test_causal_attention_matches_masked_softmax(case):
     B, H, S = case
     ops = _ops()
