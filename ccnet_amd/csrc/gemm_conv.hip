@@ -1151,11 +1151,12 @@ int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, in
         //    layer is HBM-bound and its epilogue, not its K loop, sets the time -- persistent with the residual tile
         //    prefetched at the start of the K loop (RESPRE): 391 vs 341 TFLOP/s;
         //  * one round of them where 256x320 tiles would fill half the chip (M = 8192, Cout = K = 1280: 256 vs 128 tiles):
-        //    760-830 vs 646-750 TFLOP/s; deeper K goes back to the big tile, whose K loop is the more efficient one
+        //    760-830 vs 646-750 TFLOP/s; K beyond 5120 goes back to the big tile, whose K loop is the more efficient one
         if ((Cout % 320) == 0 && batch == 1) {
             const long long t128 = tiles(128, 320);
             if (res_only && KT <= 5 && t128 >= 512) return 30;
-            if (t128 > 128 && t128 <= 256 && tiles(256, 320) < 200 && KT <= 24 && KT >= 10) return 29;
+            // (K up to 5120: ff.linear2 of the 16x16 level 995 vs 936 TFLOP/s, with residual 964 vs 915; at K = 11520 the big tile wins 1144 vs 962)
+            if (t128 > 128 && t128 <= 256 && tiles(256, 320) < 200 && KT <= 80 && KT >= 10) return 29;
         }
         if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
         if ((Cout % 256) == 0 && (Cout % 320) != 0 && tiles(256, 256) >= 150) return Cout == 256 ? 10 : 20;
