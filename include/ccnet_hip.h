@@ -250,7 +250,8 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t*
 /* Tuning switches for A/B timing (tools/, bench.py; CCNET_HIP_OPTIONS="key=value,..." sets them at load): key 0 forces a conv
  * tile configuration (-1 = planned), 2 the tile order, 3 the split-K factor, 4 persistent launches (0 off, > 1 = K limit),
  * 6 the one-pass GroupNorm paths, 7 the attention instance (0 by shape, 1 round-1 kernel, 2 long-key instance wherever it
- * applies), 8 the streaming pointwise kernel (0 off; bits: 1 on, 2 several cout groups, 4 GEGLU, 8 the 640-channel instance).  Results do not depend on
+ * applies), 8 the streaming pointwise kernel (0 off; bits: 1 on, 2 several cout groups, 4 GEGLU, 8 the 640-channel instance, 16 LayerNorm
+ * statistics in the kernel: without it a colsum-only problem returns CCNET_EUNSUP).  Results do not depend on
  * any of them beyond the order of fp32 sums inside a tile (the streaming kernel is bit-identical to the tiled one). */
 int ccnet_set_option(int key, int value);
 int ccnet_prof_enable(int on);
