@@ -281,8 +281,23 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attn_d64_w64_kernel(const AttnA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    // XCD-aware order: blocks go to the 8 XCDs round-robin by their linear index, so the query blocks of one (image, head)
+    // would land on all eight and each L2 would fetch that head's K / V; instead XCD x walks the heads bh = x, x + 8, ...,
+    // all query blocks of a head in a row (needs a head count divisible by 8; otherwise the plain order)
+    int b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+#ifndef ATTN_NO_XCD
+    {
+        const int QB = gridDim.x, HB = gridDim.y * gridDim.z;
+        if ((HB & 7) == 0) {
+            const int L = blockIdx.x + QB * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int xcd = L & 7, idx = L >> 3, bh = (idx / QB) * 8 + xcd;
+            qb = idx % QB;
+            h = bh % gridDim.y;
+            b = bh / gridDim.y;
+        }
+    }
+#endif
+    const int q0 = qb * 256 + wave * 64;
     const bool wok = q0 < a.Sq;  // wave-uniform (Sq % 64 == 0); a wave beyond Sq still stages tiles and meets the barriers
 
     // Q^T fragments (B operand) of the two query blocks
