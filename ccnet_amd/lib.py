@@ -27,7 +27,7 @@ EXPORTS = [
     "ccnet_im2col_t_bf16", "ccnet_im2col_t_nchw_f32", "ccnet_colsum_bf16", "ccnet_groupnorm_bwd_bf16",
     "ccnet_layernorm_bwd_bf16", "ccnet_softmax_bwd_rows_bf16", "ccnet_geglu_bwd_bf16", "ccnet_silu_bf16", "ccnet_axpby_bf16",
     "ccnet_resample_bwd_bf16", "ccnet_attention_d64_lse_bf16", "ccnet_attention_d64_bwd_bf16",
-    "ccnet_attention_d64_prescaled_bf16",
+    "ccnet_attention_d64_prescaled_bf16", "ccnet_ff_geglu_fused_bf16", "ccnet_ff_packed_bytes",
 ]
 
 
@@ -116,6 +116,9 @@ def load() -> C.CDLL:
     lib.ccnet_resample_bwd_bf16.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, vp]
     lib.ccnet_attention_d64_lse_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, i, i, i, i, f, vp, vp]
     lib.ccnet_attention_d64_bwd_bf16.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, i, i, f, vp]
+    lib.ccnet_ff_geglu_fused_bf16.argtypes = [vp, vp]
+    lib.ccnet_ff_packed_bytes.argtypes = [i, i]
+    lib.ccnet_ff_packed_bytes.restype = C.c_int64
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -205,6 +205,50 @@ def geglu_interleave(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([a.reshape(sh), g.reshape(sh)], dim=1).reshape(w.shape).contiguous()
 
 
+def ff_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
+    """MLPBlock(act="GEGLU") weights in the staging order of ccnet_ff_geglu_fused_bf16 (include/ccnet_hip.h), or None when
+    the kernel does not cover the shape.  w1 [2H, C] / b1 [2H] (value half first, gate half second), w2 [C, H].
+    Returns (w_packed bf16 [H/16, 15360], b1 interleaved fp32 [2H])."""
+    H2, Cc = w1.shape
+    H = H2 // 2
+    if _l.load().ccnet_ff_packed_bytes(Cc, H) == 0:
+        return None
+    dev = w1.device
+    nb = H // 16
+    w1i = geglu_interleave(w1.detach().float()).to(BF16).reshape(nb, 32, Cc // 8, 8)  # [block][row][16-byte unit][8]
+    r = torch.arange(32, device=dev)
+    pos = torch.arange(Cc // 8, device=dev)
+    src = pos[None, :] ^ ((r[:, None] >> 1) & 7)                                        # position p of row r holds unit p ^ swz(r)
+    img1 = w1i[:, r[:, None], src]                                                      # [nb, 32, units, 8]
+    t = torch.arange(8, device=dev)
+    hmap = torch.stack([torch.where(t < 4, 4 * hh + t, 4 + 4 * hh + t) for hh in (0, 1)])  # [2, 8]
+    w2b = w2.detach().to(BF16).reshape(Cc, nb, 16)                                      # [cout][block][hidden in block]
+    img2 = w2b[:, :, hmap].permute(1, 2, 0, 3)                                          # [nb, 2, cout, 8]
+    wp = torch.cat([img1.reshape(nb, -1), img2.reshape(nb, -1)], dim=1).contiguous()
+    return wp, geglu_interleave(b1.detach().float()).contiguous()
+
+
+class FfParams(C.Structure):
+    """Mirror of `ccnet_ff_params` (include/ccnet_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("w_packed", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32),
+                ("ldx", C.c_int32), ("ldo", C.c_int32), ("eps", C.c_float)]
+
+
+def ff_fused(x2d: torch.Tensor, Cc: int, pack, b2: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+             eps: float = 1e-5) -> torch.Tensor:
+    """x + linear2(GEGLU(linear1(LayerNorm(x)))) in one kernel; `pack` from ff_pack (not None)."""
+    lib = _l.load()
+    _need_cuda(x2d, pack[0])
+    out = torch.empty((x2d.shape[0], Cc), dtype=BF16, device=x2d.device)
+    p = FfParams()
+    p.x = x2d.data_ptr(); p.w_packed = pack[0].data_ptr(); p.b1 = pack[1].data_ptr(); p.b2 = b2.data_ptr()
+    p.gamma = gamma.data_ptr(); p.beta = beta.data_ptr(); p.out = out.data_ptr()
+    p.M = x2d.shape[0]; p.C = Cc; p.hidden = pack[1].numel() // 2; p.ldx = x2d.stride(0); p.ldo = out.stride(0); p.eps = eps
+    _l.check(lib.ccnet_ff_geglu_fused_bf16(C.byref(p), _stream()), "ff_geglu_fused")
+    return out
+
+
 def groupnorm(x: Act, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
               x2: Optional[Act] = None) -> Act:
     lib = _l.load()

@@ -121,6 +121,34 @@ size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p /*host*/);
 #define CCNET_NOALLOC_SCRATCH_BYTES (96u << 20) /* 96 MiB: SD-2.1 geometry up to 16 images per batch (CFG batch 32) */
 int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p /*host*/, void* stream);
 
+/* Feed-forward block of a BasicTransformerBlock in one kernel:
+ *   out[m] = x[m] + linear2( a * gelu_erf(g) ),  (a | g) = linear1( LayerNorm(x[m]; gamma, beta, eps) )
+ * Replaces `x = ff(norm3(x)) + x` of monai-generative's BasicTransformerBlock = nn.LayerNorm -> MLPBlock(act="GEGLU")
+ * (linear1: C -> 8C, chunk, a * gelu(g), linear2: 4C -> C) + the residual add, reached from util.py:944 (ControlNet.forward)
+ * and util.py:1062 (DiffusionModelUNet.forward); three ccnet_* launches otherwise (ccnet_layernorm_bf16, ccnet_conv_gemm_bf16
+ * with act = 2, ccnet_conv_gemm_bf16 with res1).  The normalised rows and the hidden tensor never reach HBM.
+ * Covers C = 320, hidden = 1280 (the 64x64 level of the SD-2.1 geometry); other shapes return CCNET_EUNSUP and the caller
+ * runs the three launches.  w_packed: both weight matrices in the kernel's staging order, ccnet_ff_packed_bytes(C, hidden)
+ * bytes (0: shape not covered), per block j of 16 hidden units:
+ *   [32 rows][320] bf16: rows (a_{16j..16j+7}, g_{16j..16j+7}, a_{16j+8..16j+15}, g_{16j+8..16j+15}) of linear1.weight, the
+ *                        16-byte unit u of row r stored at position u ^ ((r >> 1) & 7);
+ *   [2][320][8] bf16:    entry (hh, n, t) = linear2.weight[n][16 j + (t < 4 ? 4 hh + t : 4 + 4 hh + t)];
+ * b1: linear1.bias in the same row order as the first image ([2 * hidden]); b2: linear2.bias [C]. */
+typedef struct ccnet_ff_params {
+    const void* x;        /* bf16 [M][ldx]: the block's input rows (also the residual)            */
+    const void* w_packed; /* bf16, see above                                                      */
+    const float* b1;      /* [2 * hidden], interleaved as the rows of the linear1 image           */
+    const float* b2;      /* [C]                                                                  */
+    const float* gamma;   /* LayerNorm weight [C]                                                 */
+    const float* beta;    /* LayerNorm bias [C]                                                   */
+    void* out;            /* bf16 [M][ldo]                                                        */
+    int32_t M, C, hidden; /* rows, channels, hidden width (4 C)                                   */
+    int32_t ldx, ldo;     /* row strides in elements (multiples of 8)                             */
+    float eps;            /* LayerNorm epsilon                                                    */
+} ccnet_ff_params;
+int ccnet_ff_geglu_fused_bf16(const ccnet_ff_params* p /*host*/, void* stream);
+int64_t ccnet_ff_packed_bytes(int C, int hidden);
+
 /* Direct 3x3 convolution for tiny channel counts at the network edges.
  *   conv_in_small : x fp32 NCHW [Nsrc][Cin<=8][H][W] (image n reads x[n % Nsrc]) -> NHWC bf16 [N][Hout][Wout][ldo]
  *                   out = act(conv(x) + bias) + res[n % Nres]   (res NHWC bf16, optional)

@@ -865,3 +865,52 @@ def test_embed_tokens():
     out = ops.embed_tokens(ids, 77, tok, pos).float()
     ref = (tok[ids] + pos.repeat(4, 1)).to(torch.bfloat16).float()
     assert torch.equal(out, ref)
+
+
+def _ff_inputs(M, extra, cuda, seed=123):
+    g = torch.Generator().manual_seed(seed)
+    C_, Hd = 320, 1280
+    xs = torch.randn(M, C_ + extra, generator=g)
+    xs[1::7] += 20.0   # rows with a large mean (two-pass statistics)
+    xs[5::11] *= 3.0
+    x = xs.to(torch.bfloat16).to(cuda)[:, extra:]
+    gamma, beta = 1 + 0.2 * torch.randn(C_, generator=g), 0.3 * torch.randn(C_, generator=g)
+    w1 = torch.randn(2 * Hd, C_, generator=g) / math.sqrt(C_)
+    b1 = 0.5 * torch.randn(2 * Hd, generator=g)
+    w2 = torch.randn(C_, Hd, generator=g) * (0.5 / math.sqrt(Hd))
+    b2 = 0.5 * torch.randn(C_, generator=g)
+    return x, gamma.to(cuda), beta.to(cuda), w1.to(cuda), b1.to(cuda), w2.to(cuda), b2.to(cuda)
+
+
+@pytest.mark.parametrize("case", [(128, 0), (677, 0), (4096 + 37, 64), (32768, 0), (131072, 0)])
+def test_ff_fused_320(cuda, case):
+    """x + linear2(GEGLU(linear1(LayerNorm(x)))) in one kernel (ccnet_ff_geglu_fused_bf16; SURVEY Appendix A.3: norm3 +
+    MLPBlock(act="GEGLU") + residual) at the G1 64x64-level width: against the fp32 chain F.layer_norm -> F.linear ->
+    a * gelu(g) -> F.linear -> + x on the same bf16-rounded operands, and against the three-launch path it replaces
+    (LayerNorm kernel, linear1 + GEGLU epilogue, linear2 + residual: same rounding points, so nearly every element agrees to
+    an ulp).  Row counts: one tile, ragged (not a multiple of the 128-row tile or of 32), a column view of wider rows, several
+    tiles per workgroup (131072 rows = 1024 tiles over 256 workgroups)."""
+    ops = _ops()
+    M, extra = case
+    x, gamma, beta, w1, b1, w2, b2 = _ff_inputs(M, extra, cuda)
+    pack = ops.ff_pack(w1, b1, w2)
+    assert pack is not None and pack[0].shape == (80, 15360)
+    out = ops.ff_fused(x, 320, pack, b2, gamma, beta, 1e-5)
+    w1b, w2b = w1.to(torch.bfloat16), w2.to(torch.bfloat16)
+    ln = F.layer_norm(x.float(), (320,), gamma, beta, 1e-5)
+    h = ln.to(torch.bfloat16).float() @ w1b.float().T + b1
+    hid = (h[:, :1280] * F.gelu(h[:, 1280:])).to(torch.bfloat16).float()
+    ref = hid @ w2b.float().T + b2 + x.float()
+    _close(out.float(), ref, atol=3e-2, what=f"fused feed-forward {case}")
+    t = ops.layernorm(x, 320, gamma, beta)
+    gl = ops.linear(t, ops.geglu_interleave(w1b).contiguous(), ops.geglu_interleave(b1).contiguous(), 2560, 320, act=2)
+    un = ops.linear(gl, w2b.contiguous(), b2, 320, 1280, res1=x)
+    d = (out.float() - un.float()).abs()
+    scale = un.float().abs().max().item()
+    assert d.max().item() <= 2.0 ** -6 * scale, f"vs the three-launch path: max {d.max().item()} (|out| max {scale})"
+    assert (d > 0).float().mean().item() < 0.25
+
+
+def test_ff_fused_unsupported_shape(cuda):
+    ops = _ops()
+    assert ops.ff_pack(torch.zeros(2 * 2560, 640), torch.zeros(2 * 2560), torch.zeros(640, 2560)) is None
