@@ -19,6 +19,7 @@
 // 64 B/clk/CU that path delivers) and 160 KB of HBM traffic.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +39,25 @@ constexpr int FF_PPW = FF_STAGEB / 1024 / 4;              // 1-KiB DMA pieces pe
 static_assert(FF_STAGEB % 4096 == 0, "a stage divides into whole pieces per wave");
 constexpr int FF_TAB = (2 * FF_HID + 3 * FF_C) * 4;       // b1 | gamma | beta | b2 (fp32)
 constexpr int FF_LDS = FF_NS * FF_STAGEB + FF_TAB;
+#ifndef FF_DIAG
+#define FF_DIAG 0  // timing experiments (never the shipped library): bit 0 no weight DMA in the steady state, bit 1 no GEGLU arithmetic, bit 2 one W1 fragment read per block
+#endif
+#ifndef FF_PF
+#define FF_PF 4   // weight fragments are read this many MFMA slots ahead of their use
+#endif
+
+// a * gelu_erf(g), scalar form of common.h's geglu_pk (same polynomial, same rounding)
+__device__ __forceinline__ float geglu_f(float a, float g) {
+    const float ag = fabsf(g);
+    float q = fmaf(ag, 2.9924784e-05f, -0.0007398792f);
+    q = fmaf(q, ag, 0.007977478f);
+    q = fmaf(q, ag, -0.053238206f);
+    q = fmaf(q, ag, -0.45891568f);
+    q = fmaf(q, ag, -1.1511471f);
+    q = q * ag;
+    const float e = __builtin_amdgcn_exp2f(q);
+    return a * fmaf(ag * -0.5f, e, fmaxf(g, 0.0f));
+}
 
 __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -52,21 +72,22 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
     for (int t = tid; t < FF_C; t += 256) { gms[t] = a.gamma[t]; bts[t] = a.beta[t]; b2s[t] = a.b2[t]; }
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, a.wp_bytes, 0x00020000);
-    // stage gs of this workgroup's sequence (tile after tile, FF_NSTAGE stages each) -> ring slot gs % FF_NS
-    auto issue_stage = [&](int gs) {
-        const int s = gs % FF_NSTAGE;
-        char* base = smem + (gs % FF_NS) * FF_STAGEB + wave * (FF_PPW * 1024);
+    const int my_tiles = ((int)blockIdx.x < a.tiles) ? (a.tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (my_tiles == 0) return;
+    // The stream is periodic over a tile's FF_NSTAGE stages; stage s holds, for its two hidden blocks j = 2 s, 2 s + 1, the W1 image
+    // of block j and the W2 image of block j - 1 (block -1 = block 79 of the PREVIOUS tile): linear2 runs one block behind linear1,
+    // so that GEGLU of block j - 1 (vector instructions) issues under the MFMAs of linear1 of block j.  One stage more than the
+    // tiles need is loaded: its first W2 image closes the last tile.
+    const int total_loads = my_tiles * FF_NSTAGE + 1;
+    {
+        const int s = 0;
+        char* base = smem + wave * (FF_PPW * 1024);
         const unsigned off = (unsigned)s * FF_STAGEB + (unsigned)wave * (FF_PPW * 1024) + (unsigned)lane * 16u;
 #pragma unroll
         for (int i = 0; i < FF_PPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + i * 1024), 16,
                                                      (int)(off + i * 1024), 0, 0, 0);
-    };
-
-    const int my_tiles = ((int)blockIdx.x < a.tiles) ? (a.tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    if (my_tiles == 0) return;
-    const int total_stages = my_tiles * FF_NSTAGE;
-    issue_stage(0);
+    }
 
     // W1 fragment of k-step ks = 4 m + r: row l31, 16-byte unit (2 ks + hh) ^ swz(l31) = 8 m + ((2 r) ^ (hh ^ swz)): four lane
     // bases + a literal offset
@@ -81,15 +102,103 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
         lo = r[0]; hi = r[1];
     };
 
-    int gs = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
+    bf16x8 xh[FF_KS];            // the wave's 32 normalised rows: lane holds channels 16 ks + 8 hh .. + 7 of row l31
+    f32x16 acc2[FF_C / 32];      // all 320 outputs of those rows: register (4 q + e) of block i is cout 32 i + 8 q + 4 hh + e
+    f32x16 acc1a, acc1b;         // linear1 of the even / odd hidden blocks (bias included): one waits for its GEGLU while the other accumulates
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc1b[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < FF_C / 32; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc2[i][k] = 0.f;
+
+    // One hidden block: linear1 of block j from the W1 image at w1b (20 MFMAs, one accumulation chain) with GEGLU of block j - 1
+    // and the next stage's DMA issues between them, then linear2 of block j - 1 from the W2 image at w2b (10 MFMAs).
+    // The issue order inside a block is written out slot by slot -- one MFMA per slot, followed by what should issue while it
+    // executes (an MFMA holds the SIMD's issue port for 8 of its 32 cycles): the fragment read that is FF_PF slots ahead, one DMA
+    // piece, a slice of the GEGLU chain -- with a scheduling barrier between slots, because with one wave per SIMD nothing else
+    // hides a stall and hipcc's own order clusters the MFMAs and leaves the vector work serial behind them
+    // (__builtin_amdgcn_sched_group_barrier pipelines were not honoured in this loop).
+    auto phase = [&](const char* w1b, const char* w2b, const float* bias, const f32x16& acc1p, f32x16& acc1n, auto dma, char* dma_base, unsigned dma_off) {
+        constexpr int PF = FF_PF;
+        bf16x8 fr1[FF_KS], fr2[FF_C / 32];
+        f32x4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = *(const f32x4*)(bias + 8 * q);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) fr1[k] = *(const bf16x8*)(w1b + w1off[k & 3] + (k >> 2) * 128);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1n[4 * q + e] = bv[q][e];
+        __builtin_amdgcn_sched_barrier(0);
+        // GEGLU of the previous block in 24 parts (8 elements x 3): quads (0, 1) -> hidden 4 hh + e, quads (2, 3) -> hidden
+        // 8 + 4 hh + e of the block's 16 (value rows and gate rows interleave in 8-row blocks, ops.geglu_interleave): the lane's 8
+        // results, in this order, are the k = 8 hh .. 8 hh + 7 entries of linear2's B operand (W2's image is permuted to match).
+        // a * gelu_erf(g) = a * (max(g, 0) - |g| / 2 * exp2(|g| Q(|g|))), common.h's polynomial, scalar fp32 on purpose: packed
+        // fp32 instructions cost several times their issue slot beside MFMAs.
+        float ga[8], gg[8], gq[8], gx[8], r8[8];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ga[4 * h2 + e] = acc1p[8 * h2 + e]; gg[4 * h2 + e] = acc1p[8 * h2 + 4 + e]; }
+        auto gpart = [&](int t) {
+            const int e = t & 7, part = t >> 3;
+            const float ag = fabsf(gg[e]);
+            if (FF_DIAG & 2) { r8[e] = ga[e] + gg[e]; return; }
+            if (part == 0) {
+                float q = fmaf(ag, 2.9924784e-05f, -0.0007398792f);
+                q = fmaf(q, ag, 0.007977478f);
+                gq[e] = fmaf(q, ag, -0.053238206f);
+            } else if (part == 1) {
+                float q = fmaf(gq[e], ag, -0.45891568f);
+                q = fmaf(q, ag, -1.1511471f);
+                gx[e] = __builtin_amdgcn_exp2f(q * ag);
+            } else {
+                r8[e] = ga[e] * fmaf(ag * -0.5f, gx[e], fmaxf(gg[e], 0.0f));
+            }
+        };
+        bf16x8 pf;
+#pragma unroll
+        for (int k = 0; k < FF_KS; ++k) {
+            acc1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr1[k], xh[k], acc1n, 0, 0, 0);
+            if (k + PF < FF_KS) {
+                const int kk = (FF_DIAG & 4) ? 0 : k + PF;
+                fr1[k + PF] = *(const bf16x8*)(w1b + w1off[kk & 3] + (kk >> 2) * 128);
+            } else {
+                fr2[k + PF - FF_KS] = *(const bf16x8*)(w2b + w2off + (k + PF - FF_KS) * 512);
+            }
+            if constexpr (decltype(dma)::value && !(FF_DIAG & 1)) {
+                // stage gs + 1 into the slot that the stage before this one used (every wave left it: the barrier at the top of this
+                // stage); beyond the last stage the offset falls outside the descriptor: zeros land, nothing is fetched, no branch
+                if (k >= 1 && k <= FF_PPW)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dma_base + (k - 1) * 1024), 16,
+                                                             (int)(dma_off + (k - 1) * 1024), 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = (k * 24) / FF_KS; t < ((k + 1) * 24) / FF_KS; ++t) gpart(t);
+            if (k == FF_KS - 1) pf = __builtin_bit_cast(bf16x8, pack8(r8));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < FF_C / 32; ++i) {
+            acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr2[i], pf, acc2[i], 0, 0, 0);
+            if (i + PF < FF_C / 32) fr2[i + PF] = *(const bf16x8*)(w2b + w2off + (i + PF) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int gs = 0, prow = 0;
+    bool prok = false;
+    const __bf16* pxp = a.x;
+    for (int ti = 0;; ++ti) {
+        const bool live = ti < my_tiles;
         const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
         const int row = tile * 128 + wave * 32 + l31;
-        const bool rok = row < a.M;
-        // ---- the wave's 32 rows: raw (residual) and normalised (B operand of linear1); lane holds channels 16 ks + 8 hh .. + 7
-        bf16x8 xh[FF_KS];
+        const bool rok = live && row < a.M;
         const __bf16* xp = a.x + (long long)(rok ? row : a.M - 1) * a.ldx + 8 * hh;
-        {
+        if (live) {
+            // ---- the wave's 32 rows -> LayerNorm -> bf16 (two-pass statistics over the lane's 160 values + its lane ^ 32 partner's)
             u32x4 xr[FF_KS];
 #pragma unroll
             for (int ks = 0; ks < FF_KS; ++ks) xr[ks] = *(const u32x4*)(xp + 16 * ks);
@@ -131,90 +240,78 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
                 xh[ks] = __builtin_bit_cast(bf16x8, pack8(o));
             }
         }
-        // ---- output accumulators start at linear2's bias: register (4 q + e) of block i is cout 32 i + 8 q + 4 hh + e
-        f32x16 acc2[FF_C / 32];
-#pragma unroll
-        for (int i = 0; i < FF_C / 32; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = *(const f32x4*)(b2s + 32 * i + 8 * q + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc2[i][4 * q + e] = t[e];
-            }
-
-        for (int s = 0; s < FF_NSTAGE; ++s, ++gs) {
-            // stage gs has landed (this wave's pieces: vmcnt; the others': barrier) and every wave has left stage gs - 1,
-            // whose slot takes stage gs + 1
+        // stage gs: wait until it has landed (this wave's pieces: vmcnt; the others': barrier; every wave has then also left stage
+        // gs - 1, whose slot takes stage gs + 1), then its two hidden blocks
+        auto stage_head = [&](int s, const char*& sb, char*& dma_base, unsigned& dma_off) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (gs + 1 < total_stages) issue_stage(gs + 1);
-            const char* sb = smem + (gs % FF_NS) * FF_STAGEB;
-            f32x16 acc1[FF_HB];
-#pragma unroll
-            for (int hb = 0; hb < FF_HB; ++hb) {
-                const char* w1b = sb + hb * FF_BLKB;
-                const float* bb = b1s + (s * FF_HB + hb) * 32 + 4 * hh;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t = *(const f32x4*)(bb + 8 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc1[hb][4 * q + e] = t[e];
-                }
-#pragma unroll
-                for (int ks = 0; ks < FF_KS; ++ks) {
-                    const bf16x8 af = *(const bf16x8*)(w1b + w1off[ks & 3] + (ks >> 2) * 128);
-                    acc1[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xh[ks], acc1[hb], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int hb = 0; hb < FF_HB; ++hb) {
-                // GEGLU: quads (0, 1) -> hidden 4 hh + e, quads (2, 3) -> hidden 8 + 4 hh + e of the block's 16 (value rows and
-                // gate rows interleave in 8-row blocks, ops.geglu_interleave): the lane's 8 results, in this order, are the
-                // k = 8 hh .. 8 hh + 7 entries of linear2's B operand (W2's image is permuted to match)
-                float r8[8];
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        const f32x16& v = acc1[hb];
-                        const f32x2 r = geglu_pk(f32x2{v[8 * h2 + e], v[8 * h2 + e + 1]}, f32x2{v[8 * h2 + 4 + e], v[8 * h2 + 5 + e]});
-                        r8[4 * h2 + e] = r[0];
-                        r8[4 * h2 + e + 1] = r[1];
-                    }
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pack8(r8));
-                const char* w2b = sb + hb * FF_BLKB + FF_W1B + w2off;
+            sb = smem + (gs % FF_NS) * FF_STAGEB;
+            const int gnext = gs + 1;
+            dma_base = smem + (gnext % FF_NS) * FF_STAGEB + wave * (FF_PPW * 1024);
+            dma_off = (unsigned)(gnext % FF_NSTAGE) * FF_STAGEB + (unsigned)wave * (FF_PPW * 1024) + (unsigned)lane * 16u;
+            dma_off |= gnext < total_loads ? 0u : 0x80000000u;
+        };
+        {   // ---- stage 0: between its two blocks the PREVIOUS tile ends
+            const char* sb; char* dma_base; unsigned dma_off;
+            stage_head(0, sb, dma_base, dma_off);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(sb, sb + FF_W1B, b1s + 4 * hh, acc1b, acc1a, std::true_type{}, dma_base, dma_off);
+            __builtin_amdgcn_sched_barrier(0);
+            // linear2 of the previous tile's last hidden block has just been added: that tile's outputs leave.  After the
+            // permlane32 swap a lane owns couts 32 i + 16 p + 8 hh .. + 7 of its row; the residual is the raw 16-byte unit
+            // 2 i + p of the row (re-read: L2 / Infinity Cache), one 16-byte store each.
+            if (ti > 0) {
+                __bf16* orow = a.out + (long long)prow * a.ldo + 8 * hh;
 #pragma unroll
                 for (int i = 0; i < FF_C / 32; ++i) {
-                    const bf16x8 af = *(const bf16x8*)(w2b + i * 512);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, acc2[i], 0, 0, 0);
+                    u32x4 rr[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) rr[p] = *(const u32x4*)(pxp + 32 * i + 16 * p);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        float w8[8], r8[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned lo = __float_as_uint(acc2[i][8 * p + e]), hi = __float_as_uint(acc2[i][8 * p + 4 + e]);
+                            swap32(lo, hi);
+                            w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
+                        }
+                        unpack8(rr[p], r8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w8[e] += r8[e];
+                        if (prok) *(u32x4*)(orow + 32 * i + 16 * p) = pack8(w8);
+                    }
                 }
             }
-        }
-        // ---- epilogue: after the permlane32 swap a lane owns couts 32 i + 16 p + 8 hh .. + 7 of its row: the channels of the
-        // raw 16-byte unit 2 i + p of the row (the residual: re-read, L2 / Infinity Cache), one 16-byte store each
-        __bf16* orow = a.out + (long long)row * a.ldo + 8 * hh;
+            if (!live) break;
+            // this tile's output accumulators start at linear2's bias
 #pragma unroll
-        for (int i = 0; i < FF_C / 32; ++i) {
-            u32x4 rr[2];
+            for (int i = 0; i < FF_C / 32; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) rr[p] = *(const u32x4*)(xp + 32 * i + 16 * p);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = *(const f32x4*)(b2s + 32 * i + 8 * q + 4 * hh);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                float w8[8], r8[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    unsigned lo = __float_as_uint(acc2[i][8 * p + e]), hi = __float_as_uint(acc2[i][8 * p + 4 + e]);
-                    swap32(lo, hi);
-                    w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
+                    for (int e = 0; e < 4; ++e) acc2[i][4 * q + e] = t[e];
                 }
-                unpack8(rr[p], r8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) w8[e] += r8[e];
-                if (rok) *(u32x4*)(orow + 32 * i + 16 * p) = pack8(w8);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            phase(sb + FF_BLKB, sb + FF_BLKB + FF_W1B, b1s + 32 + 4 * hh, acc1a, acc1b, std::false_type{}, nullptr, 0u);
+            __builtin_amdgcn_sched_barrier(0);
+            ++gs;
         }
+#pragma unroll 1
+        for (int s = 1; s < FF_NSTAGE; ++s, ++gs) {
+            const char* sb; char* dma_base; unsigned dma_off;
+            stage_head(s, sb, dma_base, dma_off);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(sb, sb + FF_W1B, b1s + (2 * s) * 32 + 4 * hh, acc1b, acc1a, std::true_type{}, dma_base, dma_off);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(sb + FF_BLKB, sb + FF_BLKB + FF_W1B, b1s + (2 * s + 1) * 32 + 4 * hh, acc1a, acc1b, std::false_type{}, nullptr, 0u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prow = row; prok = rok; pxp = xp;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-fill DMAs of the closing stage: no LDS write outlives the workgroup)
 }
 
 }  // namespace

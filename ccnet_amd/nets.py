@@ -44,6 +44,10 @@ LN_INLINE = os.environ.get("CCNET_LN_INLINE", "1") == "1"
 # Head dim 64: softmax scale * log2(e) folded into the packed to_q weights (one bf16 rounding of the scaled fp32 weight), the
 # attention kernel then runs its prescaled instance (no multiply in front of the exponential).  CCNET_ATTN_PRESCALE=0: A/B.
 ATTN_PRESCALE = os.environ.get("CCNET_ATTN_PRESCALE", "1") == "1"
+# CCNET_FF_FUSED=1 (default): norm3 -> ff.linear1 -> GEGLU -> ff.linear2 -> + x of the 320-channel level run as ONE launch
+# (ccnet_ff_geglu_fused_bf16: the hidden tensor never reaches HBM) where the rows fill the chip.  CCNET_FF_FUSED=0: A/B.
+FF_FUSED = os.environ.get("CCNET_FF_FUSED", "1") == "1"
+FF_FUSED_MIN_ROWS = 32768  # 128-row tiles, one workgroup per CU: below 256 tiles the three launches are faster
 
 
 def _tuple(v, n):
@@ -278,7 +282,12 @@ class _Trunk(nn.Module):
                 i_qkv = dv(ops.fold_layernorm(torch.cat([b.attn1.to_q.weight.detach().float() * qs, b.attn1.to_k.weight.detach().float(),
                                                          b.attn1.to_v.weight.detach().float()], 0), None, b.norm1.weight, b.norm1.bias))
                 i_q2 = dv(ops.fold_layernorm(b.attn2.to_q.weight.detach().float() * qs, None, b.norm2.weight, b.norm2.bias))
+            ffp = None
+            if FF_FUSED and not LN_FOLD:
+                ffp = ops.ff_pack(b.ff.linear1.weight.detach().to(dev), b.ff.linear1.bias.detach().to(dev),
+                                  b.ff.linear2.weight.detach().to(dev))  # None: width not covered by the fused kernel
             return {
+                "ffp": ffp,
                 "qkv1i": i_qkv, "q2i": i_q2,
                 "qkv1f": f_qkv, "q2f": f_q2, "ff1f": f_ff1,
                 "norm": (f32(a.norm.weight), f32(a.norm.bias)), "pin": pconv(a.proj_in.conv),
@@ -483,8 +492,13 @@ class _Trunk(nn.Module):
                 q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
             o = attend(q, kv[:, :inner], kv[:, inner:], S)
             t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
-            gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)
-        t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
+            if p["ffp"] is not None and t.shape[0] >= FF_FUSED_MIN_ROWS:
+                gl = None
+                t = ops.ff_fused(t, inner, p["ffp"], p["ff2"][1], p["ln3"][0], p["ln3"][1])
+            else:
+                gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)
+        if gl is not None:
+            t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
         ta = Act(t, x.N, x.H, x.W, inner)
         return ops.conv(ta, p["pout"][0], p["pout"][1], C_, R=1, pad=0, res1=x, res2=res2)
 

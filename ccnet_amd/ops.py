@@ -224,6 +224,7 @@ def ff_pack(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor):
     hmap = torch.stack([torch.where(t < 4, 4 * hh + t, 4 + 4 * hh + t) for hh in (0, 1)])  # [2, 8]
     w2b = w2.detach().to(BF16).reshape(Cc, nb, 16)                                      # [cout][block][hidden in block]
     img2 = w2b[:, :, hmap].permute(1, 2, 0, 3)                                          # [nb, 2, cout, 8]
+    img2 = torch.roll(img2, 1, 0)   # linear2 runs one hidden block behind linear1: block j's stage carries W2 of block j - 1 (mod nb)
     wp = torch.cat([img1.reshape(nb, -1), img2.reshape(nb, -1)], dim=1).contiguous()
     return wp, geglu_interleave(b1.detach().float()).contiguous()
 

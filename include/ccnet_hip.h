@@ -132,7 +132,8 @@ int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p /*host*/, void* stre
  * bytes (0: shape not covered), per block j of 16 hidden units:
  *   [32 rows][320] bf16: rows (a_{16j..16j+7}, g_{16j..16j+7}, a_{16j+8..16j+15}, g_{16j+8..16j+15}) of linear1.weight, the
  *                        16-byte unit u of row r stored at position u ^ ((r >> 1) & 7);
- *   [2][320][8] bf16:    entry (hh, n, t) = linear2.weight[n][16 j + (t < 4 ? 4 hh + t : 4 + 4 hh + t)];
+ *   [2][320][8] bf16:    entry (hh, n, t) = linear2.weight[n][16 j' + (t < 4 ? 4 hh + t : 4 + 4 hh + t)], j' = (j - 1) mod (hidden / 16):
+ *                        the kernel runs linear2 one hidden block behind linear1;
  * b1: linear1.bias in the same row order as the first image ([2 * hidden]); b2: linear2.bias [C]. */
 typedef struct ccnet_ff_params {
     const void* x;        /* bf16 [M][ldx]: the block's input rows (also the residual)            */
