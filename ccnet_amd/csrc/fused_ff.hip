@@ -40,7 +40,7 @@ static_assert(FF_STAGEB % 4096 == 0, "a stage divides into whole pieces per wave
 constexpr int FF_TAB = (2 * FF_HID + 3 * FF_C) * 4;       // b1 | gamma | beta | b2 (fp32)
 constexpr int FF_LDS = FF_NS * FF_STAGEB + FF_TAB;
 #ifndef FF_DIAG
-#define FF_DIAG 0  // timing experiments (never the shipped library): bit 0 no weight DMA in the steady state, bit 1 no GEGLU arithmetic, bit 2 one W1 fragment read per block
+#define FF_DIAG 0  // timing experiments (never the shipped library): bit 0 no weight DMA in the steady state, bit 1 no GEGLU arithmetic, bit 2 one W1 fragment read per block, bit 3 no wait / barrier per stage, bit 4 no LayerNorm arithmetic and no residual
 #endif
 #ifndef FF_PF
 #define FF_PF 4   // weight fragments are read this many MFMA slots ahead of their use
@@ -237,14 +237,16 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
                     o[e] = (f[e] - mean) * rstd * g0[e] + t0[e];
                     o[4 + e] = (f[4 + e] - mean) * rstd * g1[e] + t1[e];
                 }
-                xh[ks] = __builtin_bit_cast(bf16x8, pack8(o));
+                xh[ks] = (FF_DIAG & 16) ? __builtin_bit_cast(bf16x8, xr[ks]) : __builtin_bit_cast(bf16x8, pack8(o));
             }
         }
         // stage gs: wait until it has landed (this wave's pieces: vmcnt; the others': barrier; every wave has then also left stage
         // gs - 1, whose slot takes stage gs + 1), then its two hidden blocks
         auto stage_head = [&](int s, const char*& sb, char*& dma_base, unsigned& dma_off) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(FF_DIAG & 8)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             asm volatile("" ::: "memory");
             sb = smem + (gs % FF_NS) * FF_STAGEB;
             const int gnext = gs + 1;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
                 for (int i = 0; i < FF_C / 32; ++i) {
                     u32x4 rr[2];
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) rr[p] = *(const u32x4*)(pxp + 32 * i + 16 * p);
+                    for (int p = 0; p < 2; ++p) rr[p] = (FF_DIAG & 16) ? u32x4{0u, 0u, 0u, 0u} : *(const u32x4*)(pxp + 32 * i + 16 * p);
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         float w8[8], r8[8];

@@ -93,6 +93,15 @@ class Sampler:
         # durations stop meaning anything -- it is also off while bench.py brackets launches with events).
         self.overlap = overlap if overlap is not None else os.environ.get("CCNET_OVERLAP", "1") != "0"
         self._side = None
+        # guidance_scale None keeps the text half of the [uncond, text] batch and 0 the unconditional half
+        # (run_controlnet_inference.py:245-252; the reference's canonical script runs guidance_scale=0.0,
+        # src/bash/INF_CTRL_CCNET_P1.sh:21).  No operation couples the rows of a batch, so only the half that is kept is
+        # evaluated: B rows instead of 2B, the same value per image up to the order of fp32 sums (tile plans depend on
+        # the row count).  CCNET_CFG_PRUNE=0 evaluates both halves and discards one, as the reference does.
+        self.prune_cfg = os.environ.get("CCNET_CFG_PRUNE", "1") != "0"
+
+    def _one_branch(self) -> bool:
+        return self.cfg and self.prune_cfg and (self.guidance_scale is None or self.guidance_scale == 0)
 
     @torch.no_grad()
     def prepare(self, cond: torch.Tensor, prompt_embeds: torch.Tensor, empty_prompt_embeds: torch.Tensor,
@@ -102,9 +111,12 @@ class Sampler:
         if not cond.is_cuda:
             raise CcnetError("Sampler inputs must be on the GPU (no CPU path)")
         B = cond.shape[0]
-        if self.cfg:
+        two = self.cfg and not self._one_branch()
+        if two:
             # [uncond x B, text x B]: empty prompt first (run_controlnet_inference.py:207-208)
             ctx = torch.cat([empty_prompt_embeds.to(prompt_embeds).expand(B, -1, -1), prompt_embeds], dim=0)
+        elif self.cfg and self.guidance_scale is not None:  # guidance 0: the unconditional half alone
+            ctx = empty_prompt_embeds.to(prompt_embeds).expand(B, -1, -1)
         else:
             ctx = prompt_embeds
         st = {"B": B, "Bc": ctx.shape[0]}
@@ -114,7 +126,7 @@ class Sampler:
         cls = None
         if acquisition_time is not None:
             a = acquisition_time.reshape(B).float()
-            cls = (torch.cat([a, a]) if self.cfg else a).reshape(-1, 1).to(cond.device)
+            cls = (torch.cat([a, a]) if two else a).reshape(-1, 1).to(cond.device)
         st["cls"] = cls
         # every step's time-embedding projections in one batched evaluation per network ([T, Bc, channels]; None if too big)
         tables = os.environ.get("CCNET_EMB_TABLE", "1") != "0"  # (switch for A/B timing)
@@ -156,7 +168,7 @@ class Sampler:
                 index = [int(v) for v in self.scheduler.timesteps].index(int(t))
             tall_c, tall_u = st["tall_c"][index], st["tall_u"][index]
         out = self._model_output(st, x, ts, tall_c, tall_u)
-        if self.cfg:
+        if self.cfg and not self._one_branch():
             if isinstance(self.scheduler, DDPMScheduler):
                 return self.scheduler.step_cfg(out, t, x, self.guidance_scale, noise=ddpm_noise)
             return self.scheduler.step_cfg(out, t, x, self.guidance_scale)
@@ -169,10 +181,10 @@ class Sampler:
         """The step on static buffers: ControlNet -> UNet -> fused CFG + scheduler update of g["x"] in place."""
         st = g["st"]
         out = self._model_output(st, g["x"], g["ts"], g["tall_c"], g["tall_u"])
-        if self.cfg:
+        if self.cfg and not self._one_branch():
             mode, gs = _cfg_mode(self.guidance_scale)
         else:
-            mode, gs = 3, 0.0
+            mode, gs = 3, 0.0  # model_out is the prediction itself
         ops.cfg_scheduler_step(out, mode, gs, g["coef"], g["x"], noise=g["noise"])
 
     @staticmethod
@@ -198,7 +210,7 @@ class Sampler:
         key = (tuple(x.shape), st["Bc"], st["cls"] is None, st["kv_c"][1], ddpm, id(self.scheduler),
                tuple(int(t) for t in self.scheduler.timesteps[:2]), len(self.scheduler.timesteps),
                None if self.guidance_scale is None else float(self.guidance_scale), float(self.conditioning_scale),
-               bool(self.cfg), bool(self.overlap), st.get("tall_c") is not None,
+               bool(self.cfg), bool(self._one_branch()), bool(self.overlap), st.get("tall_c") is not None,
                getattr(self.scheduler, "clip_sample", None), getattr(self.scheduler, "prediction_type", None))
         g = self._graphs.get(key)
         if g is not None:

@@ -153,6 +153,44 @@ def test_sampler_parity_tiny(cuda, kind):
     assert ps_db >= 40.0
 
 
+@pytest.mark.parametrize("gs", [None, 0.0])
+def test_sampler_guidance_none_and_zero_run_one_branch(cuda, gs, monkeypatch):
+    """guidance_scale None keeps the text half of the [uncond, text] batch and 0 the unconditional half
+    (run_controlnet_inference.py:245-252; src/bash/INF_CTRL_CCNET_P1.sh:21 runs 0.0).  The Sampler evaluates only the half that
+    is kept (B rows instead of 2B): against the oracle's 2B loop, and against its own 2B form (CCNET_CFG_PRUNE=0) -- the same
+    value per image; the two forms may pick different tile plans (row count), so equality is to fp32-summation-order / bf16
+    rounding level, far below the oracle tolerance."""
+    import ccnet_amd.schedulers as ps
+    import oracle.schedulers as osch
+    from ccnet_amd.sampling import Sampler
+    from oracle.sampler import sample as osample
+    pc, oc = build_pair("controlnet", {**TINY, **TINY_CE}, 11, cuda, acq=True)
+    pu, ou = build_pair("unet", TINY, 12, cuda, acq=True)
+    B, steps = 3, 6
+    x, ctx, cond = _inputs(B, cuda, seed=24)
+    g = torch.Generator().manual_seed(25)
+    empty = 0.5 * torch.randn(1, 77, 64, generator=g)
+    acq = torch.tensor([100.0, 650.0, 333.0])
+    psch, osc = ps.DDIMScheduler(clip_sample=False, **SCHED), osch.DDIMScheduler(clip_sample=False, **SCHED)
+    psch.set_timesteps(steps)
+    osc.set_timesteps(steps)
+    args = (x.to(cuda), cond.to(cuda), ctx.to(cuda), empty.to(cuda), acq.to(cuda))
+    s = Sampler(pc, pu, psch, None, guidance_scale=gs, conditioning_scale=1.0, scale_factor=0.5)
+    assert s._one_branch()
+    st = s.prepare(*args[1:])
+    assert st["Bc"] == B  # one branch only
+    one = s.sample(*args)["latent"]
+    monkeypatch.setenv("CCNET_CFG_PRUNE", "0")
+    s2 = Sampler(pc, pu, psch, None, guidance_scale=gs, conditioning_scale=1.0, scale_factor=0.5)
+    assert not s2._one_branch() and s2.prepare(*args[1:])["Bc"] == 2 * B
+    two = s2.sample(*args)["latent"]
+    ref = osample(oc, ou, osc, x, cond, ctx, empty, guidance_scale=gs, conditioning_scale=1.0, acquisition_time=acq)["latent"]
+    e1, e2 = (one.cpu() - ref).abs().max().item(), (two.cpu() - ref).abs().max().item()
+    d = (one - two).abs().max().item()
+    print(f"guidance {gs}: one-branch vs oracle {e1:.3e}, two-branch vs oracle {e2:.3e}, one vs two {d:.3e}")
+    assert e1 <= 0.1 and e2 <= 0.1 and d <= 2e-2
+
+
 def test_g1_single_cfg_step(cuda):
     """SD-2.1-base geometry, batch 1 with CFG (effective batch 2), one DDIM step at t=980 against the oracle."""
     import ccnet_amd.schedulers as ps
