@@ -95,8 +95,11 @@ def cpu_baseline(steps_sample: int, acq: bool):
 def conv_algorithmic_bytes(M, Cout, K, R, flags):
     """Bytes one conv / linear launch has to move if every operand crosses HBM exactly once: the input pixels (not the
     im2col view), the weights, the output and the residual operands.  `flags` as in ccnet_prof_shapes: bit0 stride 2, bit1
-    nearest x2 upsample in the gather, bit3 GEGLU epilogue (output half as wide), bit4 res1, bit5 res2 + out2."""
+    nearest x2 upsample in the gather, bit3 GEGLU epilogue (output half as wide), bit4 res1, bit5 res2 + out2, bit7 the fused
+    feed-forward block (recorded as M x C x 12 C: linear1 C -> 8C and linear2 4C -> C)."""
     fl = int(flags)
+    if fl & 128:  # fused feed-forward block (ccnet_ff_geglu_fused_bf16): rows in (also the residual), both weight matrices, rows out
+        return 2.0 * (M * Cout + Cout * K + M * Cout)
     cin = K / (R * R)
     in_pixels = M * (4 if fl & 1 else 1) / (4 if fl & 2 else 1)
     cout_out = Cout / 2 if fl & 8 else Cout
@@ -116,7 +119,7 @@ def hbm_traffic_per_launch():
     import csv
     n = f = w = 0.0
     for row in csv.reader(l for l in open(files[-1]) if not l.startswith("#")):
-        if len(row) == 5 and (row[0].startswith("conv_gemm_kernel<") or row[0].startswith("pw_stream_kernel<")):
+        if len(row) == 5 and (row[0].startswith("conv_gemm_kernel<") or row[0].startswith("pw_stream_kernel<") or row[0].startswith("ff320_kernel")):
             n += float(row[1]); f += float(row[2]); w += float(row[3])
     if not n:
         return None
@@ -138,6 +141,13 @@ def launch_ranks(n: int) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # host threads: the ranks share this machine's cores (synthetic inputs and weights are drawn on the CPU), so each gets
+    # its share of what this process was allowed instead of all of it
+    try:
+        base = int(env.get("OMP_NUM_THREADS", "") or len(os.sched_getaffinity(0)))
+    except (ValueError, AttributeError):
+        base = os.cpu_count() or n
+    env["OMP_NUM_THREADS"] = str(max(1, base // n))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
     line = None
     for ln in proc.stdout:
@@ -289,7 +299,7 @@ def main():
         traffic = hbm_traffic_per_launch()
         alg_per_launch = alg_bytes / max(launches, 1)
         tb = (traffic or {}).get("bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "ccnet_conv_gemm_bf16 launches: conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA) + pw_stream_kernel (its streaming instance for the K = 320 pointwise layers)",
+        roof = {"bound": "mfma", "kernel": "conv / linear launches: conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA) + pw_stream_kernel (its streaming instance for the K = 320 / 640 pointwise layers) + ff320_kernel (fused LayerNorm -> linear1 -> GEGLU -> linear2 -> + x of the 320-channel level)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tb,
                 "traffic_unit": "bytes per launch crossing the L2 -> fabric boundary (HBM + Infinity Cache), PMC passes "

@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
 
 }  // namespace
 
+extern "C" int ccnet_prof_open(double flops, int M, int Cout, int K, int R, int flags, void* stream);  // gemm_conv.hip
+extern "C" void ccnet_prof_close(int handle, void* stream);
+
 extern "C" int ccnet_ff_geglu_fused_bf16(const ccnet_ff_params* p, void* stream) {
     if (!p || !p->x || !p->w_packed || !p->b1 || !p->b2 || !p->gamma || !p->beta || !p->out) return CCNET_EINVAL;
     if (p->M <= 0 || (p->ldx % 8) || (p->ldo % 8) || p->ldx < p->C || p->ldo < p->C) return CCNET_EINVAL;
@@ -334,8 +337,12 @@ extern "C" int ccnet_ff_geglu_fused_bf16(const ccnet_ff_params* p, void* stream)
     a.tiles = (p->M + 127) / 128;
     a.wp_bytes = (unsigned)(FF_NBLK * FF_BLKB);
     const int grid = a.tiles < 256 ? a.tiles : 256;
+    // benchmark hook (ccnet_prof_enable): recorded as an M x C x 12 C product (linear1 C -> 8C + linear2 4C -> C), flag bit 7
+    const int rec = ccnet_prof_open(2.0 * p->M * (double)FF_C * (12.0 * FF_C), p->M, FF_C, 12 * FF_C, 1, 128, stream);
     hipLaunchKernelGGL(ff320_kernel, dim3(grid), dim3(256), FF_LDS, (hipStream_t)stream, a);
-    CCNET_LAUNCH_CHECK();
+    const bool ok = hipGetLastError() == hipSuccess;
+    ccnet_prof_close(rec, stream);
+    if (!ok) return CCNET_ELAUNCH;
     return CCNET_OK;
 }
 

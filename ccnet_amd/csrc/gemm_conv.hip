@@ -1225,9 +1225,30 @@ extern "C" int ccnet_prof_collect(double* ms, double* flops, int64_t* launches) 
     return CCNET_OK;
 }
 
+// Records of other conv / linear-class kernels of the library (fused_ff.hip) in the same table: open returns a handle (0: profiling
+// off), close records the end event.
+extern "C" __attribute__((visibility("hidden"))) int ccnet_prof_open(double flops, int M, int Cout, int K, int R, int flags, void* stream) {
+    if (!g_prof_on) return 0;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (g_prof_used == g_prof.size()) {
+        ProfRec r{};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return 0;
+        g_prof.push_back(r);
+    }
+    ProfRec& rec = g_prof[g_prof_used++];
+    rec.flops = flops; rec.M = M; rec.Cout = Cout; rec.K = K; rec.R = R; rec.flags = flags;
+    (void)hipEventRecord(rec.e0, (hipStream_t)stream);
+    return (int)g_prof_used;
+}
+extern "C" __attribute__((visibility("hidden"))) void ccnet_prof_close(int handle, void* stream) {
+    if (handle <= 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if ((size_t)handle <= g_prof.size()) (void)hipEventRecord(g_prof[handle - 1].e1, (hipStream_t)stream);
+}
+
 extern "C" int ccnet_prof_shapes(double* table, int max_rows) {
     // rows of 7 doubles {M, Cout, K, R, flags, launches, ms}; flags: bit0 stride 2, bit1 upsample, bit2 two sources,
-    // bit3 GEGLU, bit4 res1, bit5 out2, bit6 batched.  Call before ccnet_prof_collect (which resets the records).
+    // bit3 GEGLU, bit4 res1, bit5 out2, bit6 batched, bit7 fused feed-forward block (fused_ff.hip).  Call before ccnet_prof_collect (which resets the records).
     int n = 0;
     for (size_t i = 0; i < g_prof_used; ++i) {
         const ProfRec& r = g_prof[i];

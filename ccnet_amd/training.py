@@ -19,6 +19,8 @@ There is no CPU or autograd fallback: without the HIP library every call raises 
 """
 from __future__ import annotations
 
+import logging
+
 import ctypes as C
 import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -729,20 +731,42 @@ def controlnet_loss_and_grads(controlnet, unet, scheduler, e: torch.Tensor, nois
 
 
 def train_step(controlnet, unet, scheduler, optimizer, e, noise, timesteps, cond, prompt_embeds, acquisition_time=None,
-               conditioning_scale: float = 1.0, snr_gamma: Optional[float] = None, clip_grad_norm_by: Optional[float] = None):
+               conditioning_scale: float = 1.0, snr_gamma: Optional[float] = None, clip_grad_norm_by: Optional[float] = None,
+               clip_grad_norm_or_value: str = "norm"):
     """The step body of train_epoch_controlnet (training_functions.py:920-1037) on latents: zero_grad, forward, loss,
-    backward, optional global-norm clipping (:1025), optimizer.step().  The parameters live in the nn.Module as upstream, so
-    any torch optimizer built over `controlnet.parameters()` applies; the packed bf16 weights are rebuilt afterwards."""
+    backward, clipping as `clip_grad` does it (util.py:1176-1206: global norm, or element-wise 'value'), then the optimizer
+    step under GradScaler.step's rule (training_functions.py:1027-1029): when the loss or any gradient is inf / NaN the update is
+    SKIPPED -- parameters, optimizer moments and the packed weights stay as they are -- and the step is logged.  There is no
+    loss scale on this path (bf16 activations), so only the skip rule of the scaler remains.  Parameters the backward did not
+    reach keep `grad = None` (the optimizer leaves them untouched, as with autograd).  The parameters live in the nn.Module as
+    upstream, so any torch optimizer built over `controlnet.parameters()` applies.  Returns (loss, gradient norm before
+    clipping -- None when nothing was clipped)."""
+    if clip_grad_norm_or_value not in ("norm", "value"):
+        raise ValueError(f"clip_grad_at {clip_grad_norm_or_value} not supported. Use 'norm' or 'value'.")  # util.py:1190
     optimizer.zero_grad(set_to_none=True)
     loss, grads = controlnet_loss_and_grads(controlnet, unet, scheduler, e, noise, timesteps, cond, prompt_embeds,
                                             acquisition_time, conditioning_scale, snr_gamma)
+    with_grad = []
     for p in controlnet.parameters():
         if p.requires_grad:
-            g = grads.get(p)
-            p.grad = g if g is not None else torch.zeros_like(p)
+            p.grad = grads.get(p)  # None where the tape recorded no gradient
+            if p.grad is not None:
+                with_grad.append(p)
+    # one fused finite-ness test over the loss and every gradient (what GradScaler.unscale_ records as found_inf)
+    norms = torch._foreach_norm([p.grad for p in with_grad]) if with_grad else []
+    total = torch.linalg.vector_norm(torch.stack([n.float() for n in norms])) if norms else loss.new_zeros(())
+    finite = bool(torch.isfinite(loss).item()) and bool(torch.isfinite(total).item())
     norm = None
+    if not finite:
+        logging.getLogger(__name__).warning("train_step: non-finite loss or gradient (loss %s, gradient norm %s): optimizer step "
+                                            "skipped", float(loss), float(total))
+        return loss, norm
     if clip_grad_norm_by is not None:
-        norm = torch.nn.utils.clip_grad_norm_(controlnet.parameters(), clip_grad_norm_by)
+        if clip_grad_norm_or_value == "norm":
+            norm = torch.nn.utils.clip_grad_norm_(with_grad, clip_grad_norm_by)
+        else:
+            norm = total
+            torch.nn.utils.clip_grad_value_(with_grad, clip_grad_norm_by)
     optimizer.step()
     controlnet._invalidate()
     return loss, norm
@@ -774,8 +798,8 @@ def train_epoch_controlnet(controlnet, diffusion, stage1, scheduler, text_encode
     accepted and unused: there is no fp16 loss scaling on this path -- activations are bf16 -- and sample logging is the
     sampler's `preview_controlnet_sample`).  Batches are dicts with the reference's keys (training_functions.py:18-23).
     Returns the list of per-step losses."""
-    if clip_grad_norm_or_value != "norm":
-        raise NotImplementedError("clip_grad_norm_or_value: only 'norm' (the reference's default)")
+    if clip_grad_norm_or_value not in ("norm", "value"):
+        raise ValueError(f"clip_grad_at {clip_grad_norm_or_value} not supported. Use 'norm' or 'value'.")  # util.py:1190
     losses = []
     for x in loader:
         images = x["target"].to(device)
@@ -787,7 +811,7 @@ def train_epoch_controlnet(controlnet, diffusion, stage1, scheduler, text_encode
         prompt_embeds = text_encoder(reports.squeeze(1))[0]
         noise = torch.randn_like(e)
         loss, _ = train_step(controlnet, diffusion, scheduler, optimizer, e, noise, timesteps, cond, prompt_embeds, acq,
-                             controlnet_conditioning_scale, snr_gamma, clip_grad_norm_by)
+                             controlnet_conditioning_scale, snr_gamma, clip_grad_norm_by, clip_grad_norm_or_value)
         if lr_scheduler is not None:
             lr_scheduler.step()
         losses.append(float(loss))

@@ -316,6 +316,37 @@ def test_train_step_reduces_the_loss(cuda):
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters()))
 
 
+def test_train_step_skips_the_update_on_non_finite_gradients_and_clips_by_value(cuda):
+    """GradScaler.step's rule (training_functions.py:1027-1029): a step whose loss / gradients are inf or NaN leaves the
+    parameters and the optimizer state untouched; `clip_grad_norm_or_value='value'` (util.py:1186-1188) clamps every gradient
+    element; an unknown mode raises the reference's ValueError."""
+    from ccnet_amd import schedulers as psch
+    from ccnet_amd import training
+    B = 2
+    cfg = dict(TINY, **TINY_CE)
+    cn, _ = build_pair("controlnet", cfg, 21, cuda, acq=True)
+    un, _ = build_pair("unet", TINY, 22, cuda, acq=True)
+    e, noise, cond, ctx, acq, t = (v.to(cuda) for v in _step_inputs(B, cuda, seed=9))
+    sch = psch.DDPMScheduler(**SCHED)
+    opt = torch.optim.AdamW(cn.parameters(), lr=2e-4)
+    before = [p.detach().clone() for p in cn.parameters()]
+    bad = e.clone()
+    bad[0, 0, 0, 0] = float("nan")
+    loss, norm = training.train_step(cn, un, sch, opt, bad, noise, t, cond, ctx, acq.unsqueeze(0), clip_grad_norm_by=1.0)
+    assert not math.isfinite(float(loss)) and norm is None
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters())), "a non-finite step must not touch the weights"
+    assert len(opt.state) == 0, "a skipped step must not create optimizer moments"
+    loss, norm = training.train_step(cn, un, sch, opt, e, noise, t, cond, ctx, acq.unsqueeze(0), clip_grad_norm_by=1e-4,
+                                     clip_grad_norm_or_value="value")
+    assert math.isfinite(float(loss)) and float(norm) > 1e-4
+    gmax = max(float(p.grad.abs().max()) for p in cn.parameters() if p.grad is not None)
+    assert gmax <= 1e-4 * (1 + 1e-6), gmax
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters()))
+    with pytest.raises(ValueError):
+        training.train_step(cn, un, sch, opt, e, noise, t, cond, ctx, acq.unsqueeze(0), clip_grad_norm_by=1.0,
+                            clip_grad_norm_or_value="bogus")
+
+
 def test_train_epoch_controlnet_signature(cuda):
     """train_epoch_controlnet with the reference's arguments and batch keys (training_functions.py:888-920) over two batches,
     stage 1 through Stage1Wrapper (util.py:1473-1492): finite losses, parameters move."""
