@@ -47,6 +47,12 @@ ATTN_PRESCALE = os.environ.get("CCNET_ATTN_PRESCALE", "1") == "1"
 # CCNET_FF_FUSED=1 (default): norm3 -> ff.linear1 -> GEGLU -> ff.linear2 -> + x of the 320-channel level run as ONE launch
 # (ccnet_ff_geglu_fused_bf16: the hidden tensor never reaches HBM) where the rows fill the chip.  CCNET_FF_FUSED=0: A/B.
 FF_FUSED = os.environ.get("CCNET_FF_FUSED", "1") == "1"
+# CCNET_CFG_SHARE=1 (default): under classifier-free guidance the unconditional and the text half of the [uncond x B, text x B]
+# batch (run_controlnet_inference.py:219-221: the same latent, conditioning image and acquisition time twice) are the SAME rows
+# until the first cross-attention reads the prompt, so conv_in, the first resnet and the first transformer block up to attn2's
+# query are evaluated once, on B rows, and duplicated there (a sampler asks for it with `_cfg_shared`).  0: A/B, both halves
+# evaluated from the start.
+CFG_SHARE = os.environ.get("CCNET_CFG_SHARE", "1") == "1"
 FF_FUSED_MIN_ROWS = 32768  # 128-row tiles, one workgroup per CU: below 256 tiles the three launches are faster
 
 
@@ -435,7 +441,7 @@ class _Trunk(nn.Module):
         off = pk["tproj_off"][id(r)]
         cout = p["cout"]
         h = ops.groupnorm(x, p["n1"][0], p["n1"][1], g, eps, True, x2=x2)
-        h = ops.conv(h, p["c1"][0], p["c1"][1], cout, R=3, rowvec=tall[:, off:off + cout])
+        h = ops.conv(h, p["c1"][0], p["c1"][1], cout, R=3, rowvec=tall[:x.N, off:off + cout])
         h = ops.groupnorm(h, p["n2"][0], p["n2"][1], g, eps, True)
         if p["skip"] is None:
             skip = x
@@ -443,7 +449,12 @@ class _Trunk(nn.Module):
             skip = ops.conv(x, p["skip"][0], p["skip"][1], cout, R=1, pad=0, x2=x2)
         return ops.conv(h, p["c2"][0], p["c2"][1], cout, R=3, res1=skip, res2=res2)
 
-    def _run_attn(self, pk, a, x: Act, kv: torch.Tensor, S: int, res2: Optional[Act] = None):
+    def _run_attn(self, pk, a, x: Act, kv: torch.Tensor, S: int, res2: Optional[Act] = None, dup_to: Optional[int] = None):
+        """dup_to: x holds the first x.N images of a batch of dup_to = 2 x.N whose halves are identical so far (CFG_SHARE): the
+        block runs on x.N images up to attn2's query and on dup_to images from the cross-attention on (kv, res2 and the result
+        have dup_to images)."""
+        if dup_to is not None and LN_FOLD:
+            x, dup_to = _dup_act(x), None
         p = pk["att"][id(a)]
         C_, inner, heads, hc = x.C, p["inner"], p["heads"], p["head_ch"]
         B, T = x.N, x.H * x.W
@@ -490,6 +501,8 @@ class _Trunk(nn.Module):
                 q = ops.linear(t, w, b, inner, inner, colsum=cs)
             else:
                 q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
+            if dup_to is not None:  # from here on the two halves differ (their prompts do)
+                q, t, x, B = torch.cat([q, q]), torch.cat([t, t]), _dup_act(x), dup_to
             o = attend(q, kv[:, :inner], kv[:, inner:], S)
             t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
             if p["ffp"] is not None and t.shape[0] >= FF_FUSED_MIN_ROWS:
@@ -502,9 +515,11 @@ class _Trunk(nn.Module):
         ta = Act(t, x.N, x.H, x.W, inner)
         return ops.conv(ta, p["pout"][0], p["pout"][1], C_, R=1, pad=0, res1=x, res2=res2)
 
-    def _encode(self, pk, h: Act, tall, kvs, S, add: Optional[Sequence[Act]] = None):
+    def _encode(self, pk, h: Act, tall, kvs, S, add: Optional[Sequence[Act]] = None, dup_to: Optional[int] = None):
         """Down blocks. Returns (h, skips); when `add` is given skips[k] = s_k + add[k] (written by the same launch
-        that produces s_k) while the trunk continues with the un-added s_k, as upstream does."""
+        that produces s_k) while the trunk continues with the un-added s_k, as upstream does.  dup_to: see _run_attn -- h
+        holds half the batch; the first resnet and the head of the first transformer block run on it (only asked for when the
+        first level has attention)."""
         skips: List[Act] = []
         k = 1  # skip 0 is the conv_in output, handled by the caller
         ai = 0
@@ -526,7 +541,8 @@ class _Trunk(nn.Module):
                 r2 = add[k] if (add is not None) else None
                 if has_att:
                     h = self._run_resnet(pk, r, h, tall)
-                    h = pick(self._run_attn(pk, blk.attentions[j], h, kvs[ai], S, res2=r2))
+                    h = pick(self._run_attn(pk, blk.attentions[j], h, kvs[ai], S, res2=r2, dup_to=dup_to))
+                    dup_to = None
                     ai += 1
                 else:
                     h = pick(self._run_resnet(pk, r, h, tall, res2=r2))
@@ -536,11 +552,21 @@ class _Trunk(nn.Module):
                 h = pick(ops.conv(h, w, b, h.C, R=3, stride=2, res2=r2))
         return h, skips, ai
 
+    def _share_ok(self, asked: bool, Bx: int, B: int) -> bool:
+        """Whether the CFG halves share their head (CFG_SHARE): the caller vouches for equal inputs, x holds one half, and the
+        first level has a transformer block to duplicate in."""
+        return bool(asked) and CFG_SHARE and B == 2 * Bx and hasattr(self.down_blocks[0], "attentions")
+
     def _mid(self, pk, h, tall, kv, S, res2=None):
         m = self.middle_block
         h = self._run_resnet(pk, m.resnet_1, h, tall)
         h = self._run_attn(pk, m.attention, h, kv, S)
         return self._run_resnet(pk, m.resnet_2, h, tall, res2=res2)
+
+
+def _dup_act(a: Act) -> Act:
+    """[a; a] along the batch: the two halves of a CFG batch that are identical so far (CFG_SHARE)."""
+    return Act(torch.cat([a.t, a.t]), 2 * a.N, a.H, a.W, a.C)
 
 
 def _as_act(t, N, dev) -> Act:
@@ -626,9 +652,11 @@ class DiffusionModelUNet(_Trunk):
     @torch.no_grad()
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
                 class_labels: Optional[torch.Tensor] = None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, _ctx_kv=None, _x_batch: Optional[int] = None, _tall=None):
+                mid_block_additional_residual=None, _ctx_kv=None, _x_batch: Optional[int] = None, _tall=None,
+                _cfg_shared: bool = False):
         """x fp32 NCHW [Bx, Cin, h, w]; the network batch is `_x_batch or Bx` (image n reads x[n % Bx], which lets a
-        CFG sampler pass the un-duplicated latent).  Returns fp32 NCHW [B, Cout, h, w]."""
+        CFG sampler pass the un-duplicated latent).  _cfg_shared: the caller guarantees that images n and n + Bx also share
+        class label and timestep (CFG_SHARE above).  Returns fp32 NCHW [B, Cout, h, w]."""
         pk = self._pk or self._pack()
         dev = pk["freqs"].device
         if not x.is_cuda:
@@ -645,12 +673,13 @@ class DiffusionModelUNet(_Trunk):
         if down_block_additional_residuals is not None:
             add = [_as_act(t, B, dev) for t in down_block_additional_residuals]
         w, b = pk["conv_in"]
-        h = ops.conv_in_small(x, B, w, b, c0, c0)
+        dup_to = B if self._share_ok(_cfg_shared, x.shape[0], B) else None
+        h = ops.conv_in_small(x, x.shape[0] if dup_to else B, w, b, c0, c0)
         if add is not None:
             s0 = ops.conv_in_small(x, B, w, b, c0, c0, res=add[0])
         else:
-            s0 = h
-        h, skips, ai = self._encode(pk, h, tall, kvs, S, add)
+            s0 = _dup_act(h) if dup_to else h
+        h, skips, ai = self._encode(pk, h, tall, kvs, S, add, dup_to=dup_to)
         skips = [s0] + skips
         if add is not None and len(add) != len(skips):
             raise ValueError(f"expected {len(skips)} down_block_additional_residuals, got {len(add)}")
@@ -685,7 +714,7 @@ class DiffusionModelUNet(_Trunk):
     @torch.no_grad()
     def encode_phase(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
                      class_labels: Optional[torch.Tensor] = None, _ctx_kv=None, _x_batch: Optional[int] = None,
-                     _tall=None):
+                     _tall=None, _cfg_shared: bool = False):
         pk = self._pk or self._pack()
         if not x.is_cuda:
             raise CcnetError("ccnet_amd.DiffusionModelUNet runs on the GPU only (no CPU fallback)")
@@ -695,10 +724,11 @@ class DiffusionModelUNet(_Trunk):
         kvs, S = self.context_kv(context) if _ctx_kv is None else _ctx_kv
         c0 = self.block_out_channels[0]
         w, b = pk["conv_in"]
-        s0 = ops.conv_in_small(x, B, w, b, c0, c0)
-        h, skips, ai = self._encode(pk, s0, tall, kvs, S, None)
+        dup_to = B if self._share_ok(_cfg_shared, x.shape[0], B) else None
+        s0 = ops.conv_in_small(x, x.shape[0] if dup_to else B, w, b, c0, c0)
+        h, skips, ai = self._encode(pk, s0, tall, kvs, S, None, dup_to=dup_to)
         h = self._mid(pk, h, tall, kvs[ai], S)
-        return {"pk": pk, "tall": tall, "kvs": kvs, "S": S, "ai": ai + 1, "skips": [s0] + skips, "h": h}
+        return {"pk": pk, "tall": tall, "kvs": kvs, "S": S, "ai": ai + 1, "skips": [_dup_act(s0) if dup_to else s0] + skips, "h": h}
 
     @torch.no_grad()
     def decode_phase(self, st, skips: Optional[Sequence[Act]] = None, h: Optional[Act] = None) -> torch.Tensor:
@@ -785,7 +815,8 @@ class ControlNet(_Trunk):
     @torch.no_grad()
     def forward_native(self, x, timesteps, controlnet_cond, conditioning_scale: float = 1.0, context=None,
                        class_labels=None, _ctx_kv=None, _cond_emb: Optional[Act] = None,
-                       _x_batch: Optional[int] = None, _unet_state=None, _before_zero=None, _tall=None):
+                       _x_batch: Optional[int] = None, _unet_state=None, _before_zero=None, _tall=None,
+                       _cfg_shared: bool = False):
         """Same computation as forward(); returns the residuals as NHWC bf16 `Act`s.  With `_unet_state` (the result of
         DiffusionModelUNet.encode_phase on the same inputs) the zero-convolutions add the UNet's skips / middle output
         in their epilogue and the returned tensors are skip + residual, ready for decode_phase(); `_before_zero()` is
@@ -803,9 +834,10 @@ class ControlNet(_Trunk):
         ce = _cond_emb if _cond_emb is not None else self.cond_embedding(controlnet_cond)
         c0 = self.block_out_channels[0]
         w, b = pk["conv_in"]
-        h = ops.conv_in_small(x, B, w, b, c0, c0, res=ce)  # h = conv_in(x) + cond_emb (image n uses ce[n % ce.N])
-        s0 = h
-        h, skips, ai = self._encode(pk, h, tall, kvs, S)
+        dup_to = B if self._share_ok(_cfg_shared, x.shape[0], B) else None
+        h = ops.conv_in_small(x, x.shape[0] if dup_to else B, w, b, c0, c0, res=ce)  # h = conv_in(x) + cond_emb (image n uses ce[n % ce.N])
+        s0 = _dup_act(h) if dup_to else h
+        h, skips, ai = self._encode(pk, h, tall, kvs, S, dup_to=dup_to)
         skips = [s0] + skips
         h = self._mid(pk, h, tall, kvs[ai], S)
         sc = float(conditioning_scale)

@@ -137,12 +137,16 @@ class Sampler:
     def _model_output(self, st, x: torch.Tensor, ts: torch.Tensor, tall_c=None, tall_u=None) -> torch.Tensor:
         """ControlNet + UNet on the latent x at timestep tensor ts -> model output fp32 [Bc, C, h, w].  tall_c / tall_u:
         this step's rows of the embedding tables of prepare() (None: the networks evaluate their embedding MLPs)."""
+        # [uncond x B, text x B] from ONE latent batch: image n and n + B share latent, conditioning image, timestep and
+        # acquisition time (prepare() builds cls as [a, a]) until the first cross-attention reads their prompts
+        shared = self.cfg and st["Bc"] == 2 * x.shape[0]
         if not self.overlap or ops.prof_is_enabled():
             down, mid = self.controlnet.forward_native(
                 x, ts, None, self.conditioning_scale, class_labels=st["cls"], _ctx_kv=st["kv_c"],
-                _cond_emb=st["cond_emb"], _x_batch=st["Bc"], _tall=tall_c)
+                _cond_emb=st["cond_emb"], _x_batch=st["Bc"], _tall=tall_c, _cfg_shared=shared)
             return self.diffusion(x, ts, class_labels=st["cls"], down_block_additional_residuals=down,
-                                  mid_block_additional_residual=mid, _ctx_kv=st["kv_u"], _x_batch=st["Bc"], _tall=tall_u)
+                                  mid_block_additional_residual=mid, _ctx_kv=st["kv_u"], _x_batch=st["Bc"], _tall=tall_u,
+                                  _cfg_shared=shared)
         cur = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=x.device)
@@ -150,11 +154,11 @@ class Sampler:
         side.wait_stream(cur)  # fork: everything the side stream touches was produced on `cur` (also inside a graph capture)
         with torch.cuda.stream(side):
             enc = self.diffusion.encode_phase(x, ts, class_labels=st["cls"], _ctx_kv=st["kv_u"], _x_batch=st["Bc"],
-                                              _tall=tall_u)
+                                              _tall=tall_u, _cfg_shared=shared)
         skips, mid = self.controlnet.forward_native(
             x, ts, None, self.conditioning_scale, class_labels=st["cls"], _ctx_kv=st["kv_c"],
             _cond_emb=st["cond_emb"], _x_batch=st["Bc"], _unet_state=enc, _before_zero=lambda: cur.wait_stream(side),
-            _tall=tall_c)
+            _tall=tall_c, _cfg_shared=shared)
         return self.diffusion.decode_phase(enc, skips, mid)
 
     @torch.no_grad()

@@ -191,6 +191,47 @@ def test_sampler_guidance_none_and_zero_run_one_branch(cuda, gs, monkeypatch):
     assert e1 <= 0.1 and e2 <= 0.1 and d <= 2e-2
 
 
+def test_cfg_halves_share_their_head(cuda, monkeypatch):
+    """Under CFG the unconditional and the text half are the same rows until the first cross-attention (same latent,
+    conditioning image, timestep, acquisition time: run_controlnet_inference.py:219-221), so the Sampler evaluates conv_in,
+    the first resnet and the first transformer block up to attn2's query once (CCNET_CFG_SHARE, nets._run_attn dup_to).
+    Against the oracle, and against the form that evaluates both halves from the start (the same values up to the order of
+    fp32 sums: tile plans depend on the row count)."""
+    import ccnet_amd.nets as pn
+    import ccnet_amd.schedulers as ps
+    import oracle.schedulers as osch
+    from ccnet_amd.sampling import Sampler
+    from oracle.sampler import sample as osample
+    pc, oc = build_pair("controlnet", {**TINY, **TINY_CE}, 11, cuda, acq=True)
+    pu, ou = build_pair("unet", TINY, 12, cuda, acq=True)
+    B, steps = 3, 6
+    x, ctx, cond = _inputs(B, cuda, seed=34)
+    g = torch.Generator().manual_seed(35)
+    empty = 0.5 * torch.randn(1, 77, 64, generator=g)
+    acq = torch.tensor([100.0, 650.0, 333.0])
+    psch, osc = ps.DDIMScheduler(clip_sample=False, **SCHED), osch.DDIMScheduler(clip_sample=False, **SCHED)
+    psch.set_timesteps(steps)
+    osc.set_timesteps(steps)
+    args = (x.to(cuda), cond.to(cuda), ctx.to(cuda), empty.to(cuda), acq.to(cuda))
+    assert pn.CFG_SHARE and pu._share_ok(True, B, 2 * B) and not pu._share_ok(True, B, B)
+    res = {}
+    dups = []
+    real_dup = pn._dup_act
+    monkeypatch.setattr(pn, "_dup_act", lambda a: (dups.append(a.N), real_dup(a))[1])
+    for overlap in (True, False):
+        res[("share", overlap)] = Sampler(pc, pu, psch, None, guidance_scale=3.0, scale_factor=0.5, overlap=overlap).sample(*args)["latent"]
+    assert dups and all(n == B for n in dups)  # the shared head ran on B images
+    monkeypatch.setattr(pn, "CFG_SHARE", False)
+    n_dup = len(dups)
+    res["plain"] = Sampler(pc, pu, psch, None, guidance_scale=3.0, scale_factor=0.5).sample(*args)["latent"]
+    assert len(dups) == n_dup
+    ref = osample(oc, ou, osc, x, cond, ctx, empty, guidance_scale=3.0, conditioning_scale=1.0, acquisition_time=acq)["latent"]
+    errs = {k: (v.cpu() - ref).abs().max().item() for k, v in res.items()}
+    d = (res[("share", True)] - res["plain"]).abs().max().item()
+    print("vs oracle:", errs, "shared vs plain:", d)
+    assert all(e <= 0.1 for e in errs.values()) and d <= 2e-2
+
+
 def test_g1_single_cfg_step(cuda):
     """SD-2.1-base geometry, batch 1 with CFG (effective batch 2), one DDIM step at t=980 against the oracle."""
     import ccnet_amd.schedulers as ps
