@@ -463,6 +463,7 @@ class _Trunk(nn.Module):
             raise CcnetError(f"attention head dim {hc}: the MI355X lowering needs num_head_channels % 64 == 0")
 
         pre = (not LN_FOLD) and p["qkv1s"] is not None
+        halves = None
 
         def attend(q, k, v, Skv):
             if hc == 64:  # flash kernel (SD-2.1 geometry)
@@ -501,10 +502,24 @@ class _Trunk(nn.Module):
                 q = ops.linear(t, w, b, inner, inner, colsum=cs)
             else:
                 q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
-            if dup_to is not None:  # from here on the two halves differ (their prompts do)
-                q, t, x, B = torch.cat([q, q]), torch.cat([t, t]), _dup_act(x), dup_to
-            o = attend(q, kv[:, :inner], kv[:, inner:], S)
-            t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
+            if dup_to is not None and hc == 64:
+                # From here on the two halves differ (their prompts do).  Nothing is copied: the cross-attention and its output
+                # projection run once per half -- the same B query / residual rows, that half's keys and values -- into the
+                # two halves of one tensor, and so does proj_out below.
+                o = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
+                t2 = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
+                rows = lambda tt, hf, n: Act(tt[hf * B * n:(hf + 1) * B * n], 1, B * n, 1, tt.shape[1])
+                for hf in (0, 1):
+                    kvh = kv[hf * B * S:(hf + 1) * B * S]
+                    ops.attention_d64(q, kvh[:, :inner], kvh[:, inner:], B, heads, T, S, scale, prescaled=pre, out=o[hf * B * T:(hf + 1) * B * T])
+                    ops.conv(rows(o, hf, T), p["o2"][0], p["o2"][1], inner, R=1, pad=0, res1=Act(t, 1, B * T, 1, inner), out=rows(t2, hf, T))
+                t, halves = t2, x
+            else:
+                halves = None
+                if dup_to is not None:
+                    q, t, x, B = torch.cat([q, q]), torch.cat([t, t]), _dup_act(x), dup_to
+                o = attend(q, kv[:, :inner], kv[:, inner:], S)
+                t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
             if p["ffp"] is not None and t.shape[0] >= FF_FUSED_MIN_ROWS:
                 gl = None
                 t = ops.ff_fused(t, inner, p["ffp"], p["ff2"][1], p["ln3"][0], p["ln3"][1])
@@ -512,6 +527,17 @@ class _Trunk(nn.Module):
                 gl = ops.linear(ops.layernorm(t, inner, *p["ln3"]), p["ff1"][0], p["ff1"][1], 8 * inner, inner, act=2)
         if gl is not None:
             t = ops.linear(gl, p["ff2"][0], p["ff2"][1], inner, 4 * inner, res1=t)
+        if not LN_FOLD and halves is not None:
+            # proj_out + the block's input (B rows, shared by the halves) [+ the ControlNet residual of each half]
+            Bh, HW = halves.N, halves.H * halves.W
+            full = ops.new_act(2 * Bh, halves.H, halves.W, C_, t.device)
+            full2 = ops.new_act(2 * Bh, halves.H, halves.W, C_, t.device) if res2 is not None else None
+            part = lambda a_, hf: Act(a_.t[hf * Bh * HW:(hf + 1) * Bh * HW], Bh, a_.H, a_.W, a_.C)
+            for hf in (0, 1):
+                ops.conv(Act(t[hf * Bh * HW:(hf + 1) * Bh * HW], Bh, halves.H, halves.W, inner), p["pout"][0], p["pout"][1], C_, R=1,
+                         pad=0, res1=halves, res2=part(res2, hf) if res2 is not None else None, out=part(full, hf),
+                         out2=part(full2, hf) if res2 is not None else None)
+            return (full, full2) if res2 is not None else full
         ta = Act(t, x.N, x.H, x.W, inner)
         return ops.conv(ta, p["pout"][0], p["pout"][1], C_, R=1, pad=0, res1=x, res2=res2)
 

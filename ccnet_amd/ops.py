@@ -57,8 +57,9 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
          res1: Optional[Act] = None, scale: float = 1.0, act: int = 0, res2: Optional[Act] = None,
          out_hw: Optional[Tuple[int, int]] = None, out: Optional[Act] = None,
          rowstat: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-         emit_stats: bool = False):
-    """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given.
+         emit_stats: bool = False, out2: Optional[Act] = None):
+    """Implicit-GEMM conv / linear. w: bf16 [Cout, R*R*(C1+C2)]. Returns Act, or (Act, Act2) when res2 is given
+    (`out` / `out2`: write into these instead of fresh tensors, e.g. row ranges of a larger one).
     rowstat / colsum: LayerNorm folded into the layer (include/ccnet_hip.h: x holds the un-normalised rows, w and bias the
     folded parameters of `fold_layernorm`, rowstat = row_stats(x) [rows, 2], or a producer's partials [rows, P, 2]).
     colsum alone: the kernel takes the statistics itself (only where `ln_inline_ok`).
@@ -77,7 +78,10 @@ def conv(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, R: in
     cout_out = Cout // 2 if act == 2 else Cout  # GEGLU epilogue halves the width
     if out is None:
         out = new_act(x.N, Ho, Wo, cout_out, x.t.device)
-    out2 = new_act(x.N, Ho, Wo, cout_out, x.t.device) if res2 is not None else None
+    if res2 is None:
+        out2 = None
+    elif out2 is None:
+        out2 = new_act(x.N, Ho, Wo, cout_out, x.t.device)
     p = _l.ConvParams()
     p.x1 = x.t.data_ptr(); p.x2 = _ptr(x2.t) if x2 is not None else None
     p.w = w.data_ptr(); p.bias = _ptr(bias); p.rowvec = _ptr(rowvec)
@@ -284,12 +288,12 @@ def geglu(x2d: torch.Tensor, Cc: int) -> torch.Tensor:
 
 
 def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
-                  scale: float, prescaled: bool = False) -> torch.Tensor:
-    """q [B*Sq, >=H*64] (views allowed), k/v [B*Skv, >=H*64] -> o [B*Sq, H*64].  prescaled: q already carries
-    scale * log2(e) (ATTN_PRESCALE, folded into the query projection by the caller); `scale` is then ignored."""
+                  scale: float, prescaled: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B*Sq, >=H*64] (views allowed), k/v [B*Skv, >=H*64] -> o [B*Sq, H*64] (`out`: write there).  prescaled: q already
+    carries scale * log2(e) (ATTN_PRESCALE, folded into the query projection by the caller); `scale` is then ignored."""
     lib = _l.load()
     _need_cuda(q, k, v)
-    o = torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
+    o = out if out is not None else torch.empty((B * Sq, H * 64), dtype=BF16, device=q.device)
     if prescaled:
         _l.check(lib.ccnet_attention_d64_prescaled_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                                         v.stride(0), o.data_ptr(), o.stride(0), B, H, Sq, Skv, _stream()),
