@@ -53,6 +53,7 @@ struct ConvArgs {
     int ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec, act;
     float scale;
     int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
+    int winM, winN;  // mfast == 2: tiles are walked in windows of winM x winN = 32 tiles (one per CU of an XCD)
     long long sx1, sw, so;
     const float* rowstat; const float* colsum;  // LayerNorm folded into the GEMM (see the accumulator start)
     int rowstat_parts; float ln_eps;            // > 0: rowstat holds that many (mean, M2) partials per row (a producer's stat_out)
@@ -151,8 +152,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
     for (int i = 0; i < NX; ++i) xsw[i] = (unsigned)((lchunk ^ swz_of(lrow + i * RPP)) << 3);
     auto setup_tile = [&](int vb) {
         const int tile = tile_of(vb);
-        m0 = (a.mfast ? tile % a.tilesM : tile / a.tilesN) * BM;
-        n0 = (a.mfast ? tile / a.tilesM : tile % a.tilesN) * BN;
+        if (a.mfast == 2) {
+            // windowed order: the 32 tiles an XCD's CUs run together are winM pixel panels x winN cout tiles, so both the pixel
+            // panels and the weight panels they share stay within that XCD's L2 (N-fastest shares one pixel panel and streams
+            // 32 weight panels through it)
+            const int w = tile >> 5, r = tile & 31, wnc = a.tilesN / a.winN;
+            const int mw = w / wnc, nw = w - mw * wnc;
+            const int rm = r / a.winN;
+            m0 = (mw * a.winM + rm) * BM;
+            n0 = (nw * a.winN + (r - rm * a.winN)) * BN;
+        } else {
+            m0 = (a.mfast ? tile % a.tilesM : tile / a.tilesN) * BM;
+            n0 = (a.mfast ? tile / a.tilesM : tile % a.tilesN) * BN;
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int m = m0 + lrow + i * RPP;
@@ -1048,6 +1060,14 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     b.tilesN = (a.Cout + BN - 1) / BN;
     b.tilesM = (a.M + BM - 1) / BM;
     b.tiles = b.tilesM * b.tilesN;
+    // windowed order wherever an XCD's 32 tiles would otherwise be 32 different weight panels (>= 8 cout tiles): measured on
+    // ff.linear1 of the 16x16 level (8192 x 10240 x 1280) 940 -> 963 TFLOP/s, with GEGLU 1039 -> 1075 (tools/bench_conv.py --cold
+    // --order 2 against --order -1, same box); g_order 0 / 1 force the N- / M-fastest walks
+    if (g_order == 2 || (g_order < 0 && b.tilesN >= 8)) {
+        b.winN = (b.tilesN % 8) == 0 ? 8 : (b.tilesN % 4) == 0 ? 4 : (b.tilesN % 2) == 0 ? 2 : 1;
+        b.winM = 32 / b.winN;
+        b.mfast = ((b.tilesM % b.winM) == 0 && (b.tiles % 256) == 0) ? 2 : 0;
+    }
     // persistent: one resident block per CU (these configurations take > 80 KB of LDS), a multiple of 8 blocks
     // (measured: +5..9 % on the K <= 1280 GEGLU / 1x1 layers, nothing beyond noise on deeper K, where a tile's
     // start-up is a small share and the hardware's dynamic block placement balances ragged tiles better)
@@ -1356,7 +1376,7 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     a.M = p->N * p->Hout * p->Wout; a.HWout = p->Hout * p->Wout;
     a.CT1 = p->C1 / 64; a.CT = (p->C1 + p->C2) / 64; a.KT = p->R * p->R * a.CT;
     a.sx1 = p->sx1; a.sw = p->sw; a.so = p->so;
-    a.mfast = g_order > 0;  // M-fastest tile order only on request: measured no better than N-fastest on any G1 layer
+    a.mfast = g_order == 1;  // M-fastest tile order only on request: measured no better than N-fastest on any G1 layer (2: windowed, set per launch)
     const long long xb1 = ((long long)p->N * p->Hin * p->Win - 1) * p->ldx1 * 2 + (long long)p->C1 * 2;
     const long long xb2 = p->C2 ? ((long long)p->N * p->Hin * p->Win - 1) * p->ldx2 * 2 + (long long)p->C2 * 2 : 0;
     const long long wb = ((long long)p->Cout - 1) * p->ldw * 2 + (long long)a.KT * 128;

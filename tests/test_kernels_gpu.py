@@ -54,6 +54,8 @@ CONV_CASES = [
     (4, 32, 32, 320, 0, 320, 3, 1, 1),   # G1 level-0 shape at reduced size -> 128x128 / 128x64 tiles
     (32, 8, 8, 1280, 0, 1280, 1, 1, 1),
     (3, 5, 5, 64, 0, 8, 1, 1, 1),
+    (32, 16, 16, 64, 0, 2560, 1, 1, 1),  # 32 x 8 tiles of 256 x 320: the windowed tile walk (4 pixel panels x 8 cout tiles per XCD)
+    (8, 32, 32, 128, 0, 5120, 1, 1, 1),  # 32 x 16 tiles, two windows per row of cout tiles
 ]
 
 
