@@ -754,7 +754,9 @@ class DiffusionModelUNet(_Trunk):
         s0 = ops.conv_in_small(x, x.shape[0] if dup_to else B, w, b, c0, c0)
         h, skips, ai = self._encode(pk, s0, tall, kvs, S, None, dup_to=dup_to)
         h = self._mid(pk, h, tall, kvs[ai], S)
-        return {"pk": pk, "tall": tall, "kvs": kvs, "S": S, "ai": ai + 1, "skips": [_dup_act(s0) if dup_to else s0] + skips, "h": h}
+        # (shared CFG head: skips[0] stays at B images -- the ControlNet's first zero-convolution adds its own half-batch
+        # residual to it and duplicates the sum; decode_phase duplicates it if no ControlNet did)
+        return {"pk": pk, "tall": tall, "kvs": kvs, "S": S, "ai": ai + 1, "skips": [s0] + skips, "h": h, "B": B}
 
     @torch.no_grad()
     def decode_phase(self, st, skips: Optional[Sequence[Act]] = None, h: Optional[Act] = None) -> torch.Tensor:
@@ -762,6 +764,8 @@ class DiffusionModelUNet(_Trunk):
         skips = st["skips"] if skips is None else skips
         if len(skips) != len(st["skips"]):
             raise ValueError(f"expected {len(st['skips'])} skips, got {len(skips)}")
+        if 2 * skips[0].N == st.get("B", skips[0].N):  # shared CFG head: the first skip is still one half
+            skips = [_dup_act(skips[0])] + list(skips[1:])
         return self._decode(st["pk"], st["h"] if h is None else h, skips, st["tall"], st["kvs"], st["S"], st["ai"])
 
 
@@ -862,7 +866,7 @@ class ControlNet(_Trunk):
         w, b = pk["conv_in"]
         dup_to = B if self._share_ok(_cfg_shared, x.shape[0], B) else None
         h = ops.conv_in_small(x, x.shape[0] if dup_to else B, w, b, c0, c0, res=ce)  # h = conv_in(x) + cond_emb (image n uses ce[n % ce.N])
-        s0 = _dup_act(h) if dup_to else h
+        s0 = h  # (shared CFG head: B images; its zero-convolution below runs on them and the result is duplicated)
         h, skips, ai = self._encode(pk, h, tall, kvs, S, dup_to=dup_to)
         skips = [s0] + skips
         h = self._mid(pk, h, tall, kvs[ai], S)
@@ -872,7 +876,11 @@ class ControlNet(_Trunk):
         us = _unet_state["skips"] if _unet_state is not None else [None] * len(skips)
         if len(us) != len(skips):
             raise ValueError(f"UNet state holds {len(us)} skips, the ControlNet produces {len(skips)}")
+        if dup_to and us[0] is not None and us[0].N != skips[0].N:
+            us = [Act(us[0].t[:skips[0].rows], skips[0].N, us[0].H, us[0].W, us[0].C)] + list(us[1:])  # (a full-batch UNet skip: its first half)
         down = [ops.conv(s, zw, zb, s.C, R=1, pad=0, scale=sc, res1=u) for s, (zw, zb), u in zip(skips, pk["zero"], us)]
+        if dup_to:
+            down[0] = _dup_act(down[0])
         zw, zb = pk["zero_mid"]
         mid = ops.conv(h, zw, zb, h.C, R=1, pad=0, scale=sc, res1=_unet_state["h"] if _unet_state is not None else None)
         return down, mid
