@@ -107,11 +107,12 @@ def test_pointwise_streaming_kernel(cuda, case):
     wk, bk = (ops.geglu_interleave(w), ops.geglu_interleave(b)) if act == 2 else (w, b)
     wk, bk = wk.contiguous().to(cuda), bk.contiguous().to(cuda)
     out = ops.conv(x, wk, bk, Cout, R=1, pad=0, res1=res, act=act)
-    assert L.load().ccnet_set_option(8, 0) == 0
+    assert L.load().ccnet_set_option(8, 0) == 0 and L.load().ccnet_set_option(9, 0) == 0  # the tiled kernel, 32x32x16 MFMA
     try:
         tiled = ops.conv(x, wk, bk, Cout, R=1, pad=0, res1=res, act=act)
     finally:
         L.load().ccnet_set_option(8, 31)
+        L.load().ccnet_set_option(9, 1)
     assert torch.equal(out.t, tiled.t), f"streaming vs tiled kernel differ: max {(out.t.float() - tiled.t.float()).abs().max().item()}"
     ref = x.t.float() @ w.float().T.to(cuda) + b.to(cuda)
     if act == 2:
@@ -152,6 +153,40 @@ def test_pointwise_streaming_layernorm_inline(cuda, case):
     assert not ops.ln_inline_ok(4096, 320, Cout)
     with pytest.raises(L.CcnetError):
         ops.linear(x[:4096], wf, bf, Cout, 320, colsum=cs)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 64, 64, 320, 0, 320, 3, 1, 1), (4, 32, 32, 640, 320, 640, 3, 1, 1),
+                                               (8, 16, 16, 1280, 0, 1280, 3, 1, 1), (32, 8, 8, 1280, 0, 1280, 3, 1, 1)])
+def test_conv_gemm_mfma_16x16x32_instances_match_32x32x16(cuda, case):
+    """Plain and split-K launches run on the v_mfma_f32_16x16x32_bf16 instances of their tile configuration
+    (conv_gemm16_kernel: the chip holds a higher clock with that shape); ccnet_set_option(9, 0) puts them back on the 32x32x16
+    kernel.  Same products, another order of fp32 sums inside the matrix core: agreement to bf16 rounding, with residual,
+    second output, SiLU, scale and the per-image row vector in the epilogue, ragged rows and partial cout tiles included."""
+    ops = _ops()
+    from ccnet_amd import lib as L
+    N, H, W, C1, C2, Cout, R, stride, ups = case
+    x1 = _rand_act(N, H, W, C1, cuda, 11)
+    x2 = _rand_act(N, H, W, C2, cuda, 12) if C2 else None
+    g = torch.Generator().manual_seed(13)
+    Cin = C1 + C2
+    wp = _pack_w(torch.randn(Cout, Cin, R, R, generator=g) / math.sqrt(Cin * R * R)).to(cuda)
+    b = torch.randn(Cout, generator=g).to(cuda)
+    Ho, Wo = H * ups // stride, W * ups // stride
+    rv = torch.randn(N, Cout, generator=g).to(cuda)
+    r1, r2 = _rand_act(N, Ho, Wo, Cout, cuda, 14), _rand_act(N, Ho, Wo, Cout, cuda, 15)
+
+    def run():
+        plain = ops.conv(x1, wp, b, Cout, R=R, stride=stride, ups=ups, x2=x2)
+        full, full2 = ops.conv(x1, wp, b, Cout, R=R, stride=stride, ups=ups, x2=x2, rowvec=rv, res1=r1, res2=r2, act=1, scale=0.7)
+        return plain.t.float(), full.t.float(), full2.t.float()
+    new = run()
+    assert L.load().ccnet_set_option(9, 0) == 0
+    try:
+        old = run()
+    finally:
+        L.load().ccnet_set_option(9, 1)
+    for nm, a_, b_ in zip(("plain", "epilogue", "second output"), new, old):
+        _close(a_, b_, atol=2e-2, what=f"16x16x32 vs 32x32x16 {nm} {case}")
 
 
 def test_conv_epilogue_full(cuda):

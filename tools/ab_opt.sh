@@ -1,10 +1,12 @@
 #!/bin/bash
-# same-box A/B of a library option over batch sizes: tools/ab_opt.sh "6=3" "1 2 4"   (CCNET_HIP_OPTIONS, see ccnet_set_option)
-OPT=$1
-python3 bench.py --batch 2 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1  # clocks up
-for B in ${2:-"1 4 16"}; do
-  for O in "" "$OPT" "" "$OPT"; do
-    v=$(CCNET_HIP_OPTIONS="$O" timeout -k 10 200 python3 bench.py --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-prof 2>&1 | grep -o '"value": [0-9.]*') || exit 1
-    echo "batch $B options '$O' $v"
-  done
+# same-box A/B of a library option on the conv shapes and on the pipeline: tools/ab_opt.sh "<key>=<a>" "<key>=<b>" ["<bench_conv filter>"]
+A=$1; B=$2; F=${3:-.}
+for O in $A $B $A $B; do
+  echo "== CCNET_HIP_OPTIONS=$O"
+  CCNET_HIP_OPTIONS=$O timeout -k 10 300 python3 tools/bench_conv.py --cold --iters 20 --filter "$F" 2>&1 | grep "us$" | awk '{printf "  %-34s %s us\n", substr($0,1,32), $(NF-1)}' || exit 1
+done
+[ -n "$NO_PIPE" ] && exit 0
+for O in $A $B $A $B; do
+  v=$(CCNET_HIP_OPTIONS=$O timeout -k 10 200 python3 bench.py --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --no-prof 2>&1 | grep -o '"value": [0-9.]*') || exit 1
+  echo "pipeline batch 16, CCNET_HIP_OPTIONS=$O: $v"
 done

@@ -36,7 +36,7 @@ def main():
     for k in sorted(fs, key=lambda k: -(2 * fs[k] + ws.get(k, 0.0))):
         n = fc[k]
         rows.append((k, n, fs[k], ws.get(k, 0.0), (2 * fs[k] + ws.get(k, 0.0)) * 1024 / n / 2 ** 20))
-    conv = [r for r in rows if r[0].startswith("conv_gemm_kernel")]
+    conv = [r for r in rows if r[0].startswith("conv_gemm_kernel")]  # (bench.py adds the pw_stream_kernel and ff320_kernel rows itself)
     with open(out, "w") as fh:
         fh.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {cmd}\n")
         fh.write("# hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reads half of a wide coalesced stream "
