@@ -1876,23 +1876,48 @@ constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices] = {};
 std::mutex g_scratch_mu;
 
-int scratch_for_current_device(void** out) {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return CCNET_ELAUNCH;
+// The array's address on device `dev` (looked up on first use, with that device current, then kept).
+int scratch_for_device(int dev, void** out) {
+    if (dev < 0 || dev >= kMaxDevices) return CCNET_ELAUNCH;
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return CCNET_ELAUNCH;
+        if (cur != dev && hipSetDevice(dev) != hipSuccess) return CCNET_ELAUNCH;
         void* ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return CCNET_ELAUNCH;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (e != hipSuccess || !ptr) return CCNET_ELAUNCH;
         g_scratch_ptr[dev] = ptr;
     }
     *out = g_scratch_ptr[dev];
     return CCNET_OK;
 }
+// The device a stream belongs to (the null stream: the current device).
+int device_of_stream(void* stream, int* dev) {
+    if (stream) {
+        hipDevice_t d;
+        if (hipStreamGetDevice((hipStream_t)stream, &d) == hipSuccess) { *dev = (int)d; return CCNET_OK; }
+    }
+    return hipGetDevice(dev) == hipSuccess ? CCNET_OK : CCNET_ELAUNCH;
+}
 }  // namespace
 
-extern "C" int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p, void* stream) {
+extern "C" int ccnet_noalloc_init(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return CCNET_ELAUNCH;
     void* ws = nullptr;
-    const int rc = scratch_for_current_device(&ws);
+    return scratch_for_device(dev, &ws);
+}
+
+extern "C" int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p, void* stream) {
+    // the array of the GPU that OWNS the stream (each GPU holds its own copy at its own address), and launches need that
+    // device current: a stream of another device than the current one is refused rather than handed a wrong pointer
+    int dev = -1, cur = -1;
+    if (device_of_stream(stream, &dev) != CCNET_OK || hipGetDevice(&cur) != hipSuccess) return CCNET_ELAUNCH;
+    if (dev != cur) return CCNET_EINVAL;
+    void* ws = nullptr;
+    const int rc = scratch_for_device(dev, &ws);
     if (rc != CCNET_OK) return rc;
     // Nothing in the array has to start at zero: every K slice writes its whole [M][Cout] slab before the reduce pass
     // reads it, so the previous call's contents are dead.  Calls that overlap on one GPU share the array and race.

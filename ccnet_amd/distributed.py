@@ -4,8 +4,9 @@ The reference samples on one GPU at batch 1 (run_controlnet_inference.py:93,212)
 path.  Images are independent units (own noise / cond / text / acquisition time, no
 batch-coupled op), so the path shards with NO data-path collective; the only exchange is one all-gather of the
 generated latents and uint8 slices for downstream FRD/FID evaluation (RCCL over xGMI when the backend is
-"nccl"; "gloo" on CPU for tests).  Noise is addressed by sample index, so results do not depend on the world
-size or on how indices are packed into batches.
+"nccl"; "gloo" on CPU for tests).  Noise is addressed by sample index, so a sample's inputs do not depend on the world
+size or on how indices are packed into batches; its output is bit-identical at equal batch size (any rank, any position in
+the batch) and agrees to bf16 rounding across batch sizes (tile plans depend on the row count).
 """
 from __future__ import annotations
 

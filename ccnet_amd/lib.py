@@ -27,12 +27,16 @@ EXPORTS = [
     "ccnet_im2col_t_bf16", "ccnet_im2col_t_nchw_f32", "ccnet_colsum_bf16", "ccnet_groupnorm_bwd_bf16",
     "ccnet_layernorm_bwd_bf16", "ccnet_softmax_bwd_rows_bf16", "ccnet_geglu_bwd_bf16", "ccnet_silu_bf16", "ccnet_axpby_bf16",
     "ccnet_resample_bwd_bf16", "ccnet_attention_d64_lse_bf16", "ccnet_attention_d64_bwd_bf16",
-    "ccnet_attention_d64_prescaled_bf16", "ccnet_ff_geglu_fused_bf16", "ccnet_ff_packed_bytes",
+    "ccnet_attention_d64_prescaled_bf16", "ccnet_ff_geglu_fused_bf16", "ccnet_ff_packed_bytes", "ccnet_noalloc_init",
 ]
 
 
 class CcnetError(RuntimeError):
     pass
+
+
+class CcnetUnsupported(CcnetError):
+    """CCNET_EUNSUP: a configuration the kernels do not cover (callers with another lowering of the same op may take it)."""
 
 
 class ConvParams(C.Structure):
@@ -134,4 +138,4 @@ def load() -> C.CDLL:
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise CcnetError(f"{what}: {load().ccnet_strerror(rc).decode()} (code {rc})")
+        raise (CcnetUnsupported if rc == -2 else CcnetError)(f"{what}: {load().ccnet_strerror(rc).decode()} (code {rc})")

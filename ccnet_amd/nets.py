@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .lib import CcnetError
+from .lib import CcnetError, CcnetUnsupported
 from .ops import Act
 
 BF16 = torch.bfloat16
@@ -490,17 +490,27 @@ class _Trunk(nn.Module):
         else:
             t = ops.conv(h, p["pin"][0], p["pin"][1], inner, R=1, pad=0).t
             inl = p["qkv1i"] is not None and ops.ln_inline_ok(t.shape[0], inner, inner)
+            qkv = None
             if inl:
+                # (the library has the last word on which launches take their LayerNorm statistics themselves -- tuning switches
+                # and descriptor limits also decide: a declined launch runs as LayerNorm kernel + plain layer)
                 w, b, cs = p["qkv1i"]
-                qkv = ops.linear(t, w, b, 3 * inner, inner, colsum=cs)
-            else:
+                try:
+                    qkv = ops.linear(t, w, b, 3 * inner, inner, colsum=cs)
+                except CcnetUnsupported:
+                    inl = False
+            if qkv is None:
                 qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1s"] if pre else p["qkv1"], None, 3 * inner, inner)
             o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
             t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
+            q = None
             if inl:
                 w, b, cs = p["q2i"]
-                q = ops.linear(t, w, b, inner, inner, colsum=cs)
-            else:
+                try:
+                    q = ops.linear(t, w, b, inner, inner, colsum=cs)
+                except CcnetUnsupported:
+                    pass
+            if q is None:
                 q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
             if dup_to is not None and hc == 64:
                 # From here on the two halves differ (their prompts do).  Nothing is copied: the cross-attention and its output

@@ -14,7 +14,11 @@ folder (no network); `--batch_size` > 1 is honoured (the reference's loop only w
 batch share one graph replay per timestep.  The initial noise of a sample is addressed by (seed, row number in the TSV)
 instead of being the next draw of the global CPU generator (:212) -- that stream also feeds the third-party model
 constructors and the loader's iterator in the reference, so it pins nothing across implementations -- which makes a run's
-images independent of batch size, of which files already existed (resume) and of how rows are split over processes: under
+INPUTS (noise, prompt, conditioning image) independent of batch size, of which files already existed (resume) and of how rows
+are split over processes.  The arithmetic applied to a row is the same function in every packing, evaluated in bf16 with
+tile plans that depend on how many rows share the batch (kernel choice, split-K factor, streaming thresholds), so the same
+row sampled in batches of different size agrees to bf16 rounding (PSNR > 40 dB between batch 1 and batch 16 at the real
+geometry, tests/test_g1_parity_gpu.py), and bit for bit only at equal batch size, in any order within the batch.  Under
 `torch.distributed.run` (WORLD_SIZE / RANK in the environment) every rank generates a contiguous block of the rows on its
 own GPU and writes its own files; there is nothing to exchange.
 """

@@ -117,8 +117,13 @@ size_t ccnet_conv_workspace_bytes(const ccnet_conv_params* p /*host*/);
  * a static device array of CCNET_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
  * A problem whose plan needs more than that returns CCNET_ESCRATCH (ccnet_conv_workspace_bytes(p) tells beforehand).
  * Calls no hipMalloc / hipFree / allocating routine; its first call on a device looks the array's address up once.
- * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams) race -- serialise them. */
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams) race -- serialise them.
+ * `stream` must belong to the CURRENT device (its GPU's copy of the array is used; a stream of another device returns
+ * CCNET_EINVAL).  ccnet_noalloc_init() looks the array's address up for the current device ahead of time -- call it once per
+ * device OUTSIDE a stream capture (the first ccnet_conv_gemm_bf16_noalloc call on a device otherwise does the lookup itself,
+ * which must not fall inside a capture). */
 #define CCNET_NOALLOC_SCRATCH_BYTES (96u << 20) /* 96 MiB: SD-2.1 geometry up to 16 images per batch (CFG batch 32) */
+int ccnet_noalloc_init(void);
 int ccnet_conv_gemm_bf16_noalloc(const ccnet_conv_params* p /*host*/, void* stream);
 
 /* Feed-forward block of a BasicTransformerBlock in one kernel:
@@ -280,7 +285,8 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t*
  * tile configuration (-1 = planned), 2 the tile order, 3 the split-K factor, 4 persistent launches (0 off, > 1 = K limit),
  * 6 the one-pass GroupNorm paths, 7 the attention instance (0 by shape, 1 round-1 kernel, 2 long-key instance wherever it
  * applies), 8 the streaming pointwise kernel (0 off; bits: 1 on, 2 several cout groups, 4 GEGLU, 8 the 640-channel instance, 16 LayerNorm
- * statistics in the kernel: without it a colsum-only problem returns CCNET_EUNSUP).  Results do not depend on
+ * statistics in the kernel: without it a colsum-only problem returns CCNET_EUNSUP), 9 the 16x16x32-MFMA instances of the tile
+ * kernel (0: every launch on the 32x32x16 instances), 2 = 2 also selects the windowed tile walk.  Results do not depend on
  * any of them beyond the order of fp32 sums inside a tile (the streaming kernel is bit-identical to the tiled one). */
 int ccnet_set_option(int key, int value);
 int ccnet_prof_enable(int on);

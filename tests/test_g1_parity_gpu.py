@@ -98,6 +98,34 @@ def test_g1_50_step_ddim_batch1_against_oracle(cuda, g1, oracle_b1):
     assert db >= 40.0
 
 
+def test_g1_guidance_zero_canonical_script_setting(cuda, g1):
+    """The reference's canonical launch script runs guidance_scale=0.0 and scale_factor=0.01 (src/bash/INF_CTRL_CCNET_P1.sh:21,30;
+    200 DDIM steps there -- tools/g1_margin.py covers all 200 against stored oracle vectors, profiles/r03_g1_margin.json): the first
+    10 steps of the 200-step schedule at the real geometry, oracle's [uncond, text] loop against the Sampler, which evaluates the
+    unconditional half alone."""
+    import ccnet_amd.schedulers as ps
+    import oracle.schedulers as osch
+    from ccnet_amd.sampling import Sampler
+    from ccnet_amd.synthetic import make_batch
+    from oracle.sampler import sample as osample
+    steps = 10
+    b = make_batch([1], seed=42, acq=True)
+    sch = ps.DDIMScheduler(clip_sample=False, **SCHED)
+    sch.set_timesteps(200)
+    s = Sampler(g1["pc"], g1["pu"], sch, None, guidance_scale=0.0, conditioning_scale=1.0, scale_factor=0.01)
+    assert s._one_branch()
+    res = _run(s, b, cuda, record_latents=True, max_steps=steps, decode=False)
+    osc = osch.DDIMScheduler(clip_sample=False, **SCHED)
+    osc.set_timesteps(200)
+    ref = osample(g1["oc"], g1["ou"], osc, b["noise"], b["cond"], b["prompt_embeds"], b["empty_prompt_embeds"],
+                  guidance_scale=0.0, conditioning_scale=1.0, acquisition_time=b["acquisition_time"], record_latents=True,
+                  max_steps=steps)
+    errs = [(a.cpu() - r).abs().max().item() for a, r in zip(res["latents"], ref["latents"])]
+    print(f"G1 guidance 0.0, {steps} of 200 steps, per-step latent max-abs:", " ".join(f"{e:.3e}" for e in errs))
+    _report("r3_g1_parity_gs0.json", {"per_step_max_abs": errs})
+    assert len(errs) == steps and max(errs) <= STEP_TOL
+
+
 def test_g1_batch16_is_index_addressed(cuda, g1, oracle_b1):
     from ccnet_amd.synthetic import make_batch
     idx = list(range(16))
