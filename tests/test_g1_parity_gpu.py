@@ -28,8 +28,14 @@ STAGE1 = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=[128, 
               num_res_blocks=2, attention_levels=[False] * 4, with_encoder_nonlocal_attn=False,
               with_decoder_nonlocal_attn=False)
 GS, CS, SF = 7.0, 1.0, 0.1  # guidance scale, conditioning scale, latent scale factor (bench.py's configuration)
-# per-step latent max-abs tolerance for bf16 compute against the fp32 oracle on O(1) latents (|x| up to ~4.5)
-STEP_TOL = 0.1
+# per-step latent max-abs tolerance for bf16 compute against the fp32 oracle on O(1) latents (|x| up to ~5.3): 1.25 x the worst
+# value measured over all 16 indices of configs[1] with the round-3 lowerings (0.0669 at step 50, tools/g1_margin.py,
+# profiles/r03_g1_margin.json; every index >= 41.5 dB PSNR)
+STEP_TOL = 0.085
+# two bf16 runs of one index that pick different tile plans (batch 1 against its row of a batch of 16): their errors against
+# the oracle are largely independent, so they sit further from each other than either sits from the oracle (41.5-42.2 dB each,
+# measured against each other 40.3-40.6 dB / latent 0.074); this is a consistency check of the batching, not the parity bar
+PAIR_TOL, PAIR_PSNR = 0.1, 39.0
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
@@ -155,7 +161,7 @@ def test_g1_batch16_is_index_addressed(cuda, g1, oracle_b1):
                                       "b16_vs_b1_latent_max_abs": worst_l, "b16_vs_b1_worst_psnr_db": worst_db,
                                       "permuted_latent_max_abs": dperm})
     assert e0 <= STEP_TOL and db0 >= 40.0
-    assert worst_l <= STEP_TOL and worst_db >= 40.0
+    assert worst_l <= PAIR_TOL and worst_db >= PAIR_PSNR
     assert dperm == 0.0  # a row's arithmetic does not depend on its position in the batch
 
 
