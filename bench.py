@@ -109,7 +109,7 @@ def conv_algorithmic_bytes(M, Cout, K, R, flags):
 
 def hbm_traffic_per_launch():
     """HBM bytes per ccnet_conv_gemm_bf16 launch from the committed PMC passes (profiles/*_hbm_traffic.csv, newest file):
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all instantiations of conv_gemm_kernel and pw_stream_kernel -- bench.py cannot collect counters
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all instantiations of conv_gemm_kernel, conv_gemm16_kernel, pw_stream_kernel and ff320_kernel -- bench.py cannot collect counters
     itself, so this is the figure of the rocprofv3 --pmc runs of this same command."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
@@ -117,13 +117,16 @@ def hbm_traffic_per_launch():
         return None
     # every launch that ccnet_conv_gemm_bf16 makes: the tiled kernel's instantiations and the streaming instance
     import csv
-    n = f = w = 0.0
+    n = f = w = rf = rw = 0.0
     for row in csv.reader(l for l in open(files[-1]) if not l.startswith("#")):
-        if len(row) == 5 and (row[0].startswith("conv_gemm_kernel<") or row[0].startswith("pw_stream_kernel<") or row[0].startswith("ff320_kernel")):
+        if len(row) == 5 and row[0].startswith(("conv_gemm_kernel<", "conv_gemm16_kernel<", "pw_stream_kernel<", "ff320_kernel")):
             n += float(row[1]); f += float(row[2]); w += float(row[3])
+        if len(row) == 5 and row[0].startswith("splitk_reduce_kernel"):  # the second launch of a split-K call: its bytes, not a call of its own
+            rf += float(row[2]); rw += float(row[3])
     if not n:
         return None
-    return {"bytes_per_launch": round((2 * f + w) * 1024 / n), "source": os.path.relpath(files[-1], ROOT)}
+    return {"bytes_per_launch": round((2 * f + w) * 1024 / n), "bytes_per_launch_with_splitk_reduce": round((2 * (f + rf) + w + rw) * 1024 / n),
+            "source": os.path.relpath(files[-1], ROOT)}
 
 
 def launch_ranks(n: int) -> int:
@@ -299,11 +302,12 @@ def main():
         traffic = hbm_traffic_per_launch()
         alg_per_launch = alg_bytes / max(launches, 1)
         tb = (traffic or {}).get("bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "conv / linear launches: conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA) + pw_stream_kernel (its streaming instance for the K = 320 / 640 pointwise layers) + ff320_kernel (fused LayerNorm -> linear1 -> GEGLU -> linear2 -> + x of the 320-channel level)",
+        roof = {"bound": "mfma", "kernel": "conv / linear launches: conv_gemm16_kernel / conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA 16x16x32 / 32x32x16) + pw_stream_kernel (its streaming instance for the K = 320 / 640 pointwise layers) + ff320_kernel (fused LayerNorm -> linear1 -> GEGLU -> linear2 -> + x of the 320-channel level)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tb,
                 "traffic_unit": "bytes per launch crossing the L2 -> fabric boundary (HBM + Infinity Cache), PMC passes "
                                 "FETCH_SIZE / WRITE_SIZE of this command, gfx950-corrected",
+                "traffic_with_splitk_reduce": (traffic or {}).get("bytes_per_launch_with_splitk_reduce"),
                 "traffic_source": (traffic or {}).get("source"),
                 # inputs once + weights once + outputs (+ residual operands), averaged over this pass's launches
                 "algorithmic_bytes": round(alg_per_launch),

@@ -53,6 +53,7 @@ struct ConvArgs {
     int ldx1, ldx2, ldw, ldo, ldo2, ldres1, ldres2, ld_rowvec, act;
     float scale;
     int M, HWout, KT, CT1, CT, tilesN, tilesM, tiles, mfast;
+    int korder;      // 1: K-steps walk (channel chunk, tap) instead of (tap, channel chunk); the weight image keeps its (tap, cin) order
     int winM, winN;  // mfast == 2: tiles are walked in windows of winM x winN = 32 tiles (one per CU of an XCD)
     long long sx1, sw, so;
     const float* rowstat; const float* colsum;  // LayerNorm folded into the GEMM (see the accumulator start)
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvArgs 
 // ds_read_b128 phase covers fall into 16 different bank groups.  Epilogue: v_permlane16_swap of the (cs = 0, cs = 1) register
 // pairs gives a lane 8 consecutive couts of one pixel -- couts 16 (g & 1) + 8 (g >> 1) .. + 7 -- i.e. one 16-byte store (and
 // residual load) per pixel sub-tile and 32-cout block; a pixel's 64 bytes of a block are written by four adjacent lanes.
-template <int WM, int WN, int TJ, int TI, int NS, bool SPLIT, bool PERSIST>
+template <int WM, int WN, int TJ, int TI, int NS, bool SPLIT, bool PERSIST, bool KORD>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm16_kernel(const ConvArgs a) {
     static_assert(!(SPLIT && PERSIST), "split-K launches are never persistent");
     constexpr int BK = 64;
@@ -704,8 +705,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm16_kernel(const ConvArg
 
     const int lrow = tid / CPW, lchunk = tid % CPW;
     auto swz_of = [](int r) { return (r >> 1) & 7; };
-    int xn[NX], xiy0[NX], xix0[NX];
+    // KORD (3x3, no upsampling): K-steps walk (channel chunk, tap) instead of (tap, channel chunk) -- the nine taps of a 64-channel
+    // chunk are consecutive steps, so the eight re-reads of a pixel's chunk hit L2 (the weight image keeps its (tap, cin) order:
+    // only the walk changes).  The tap changes every step, so a tile keeps, per gathered row, the pixel index of tap (0, 0) and one
+    // validity bit per tap: a step's gather addresses are one select + add per row.
+    static_assert(!KORD || 9 * NX <= 64, "tap validity bits of the gathered rows fit one 64-bit mask");
+    int xn[KORD ? 1 : NX], xiy0[KORD ? 1 : NX], xix0[KORD ? 1 : NX];
     unsigned xsw[NX], woff[NW];
+    int pbase[KORD ? NX : 1];
+    unsigned long long vmask = 0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) xsw[i] = (unsigned)((lchunk ^ swz_of(lrow + i * RPP)) << 3);
     auto setup_tile = [&](int vb) {
@@ -720,15 +728,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm16_kernel(const ConvArg
             m0 = (a.mfast ? tile % a.tilesM : tile / a.tilesN) * BM;
             n0 = (a.mfast ? tile / a.tilesM : tile % a.tilesN) * BN;
         }
+        if (KORD) vmask = 0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int m = m0 + lrow + i * RPP;
+            int n = -1, iy0 = 0, ix0 = 0;
             if (m < a.M) {
-                const int n = m / a.HWout, rem = m - n * a.HWout;
+                n = m / a.HWout;
+                const int rem = m - n * a.HWout;
                 const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-                xn[i] = n; xiy0[i] = oy * a.stride - a.pad; xix0[i] = ox * a.stride - a.pad;
+                iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
+            }
+            if constexpr (KORD) {
+                pbase[i] = (n * a.Hin + iy0) * a.Win + ix0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                    const bool ok = n >= 0 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+                    vmask |= (unsigned long long)ok << (t * NX + i);
+                }
             } else {
-                xn[i] = -1; xiy0[i] = 0; xix0[i] = 0;
+                xn[i] = n; xiy0[i] = iy0; xix0[i] = ix0;
             }
         }
 #pragma unroll
@@ -740,12 +760,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm16_kernel(const ConvArg
     const int Hl = a.Hin * a.ups, Wl = a.Win * a.ups, ush = a.ups >> 1;
     int pix[NX];
     auto set_tap = [&](int tap) {
-        const int kr = tap / a.R, ks = tap - kr * a.R;
+        if constexpr (KORD) {
+            const int kr = (tap * 11) >> 5, ks = tap - 3 * kr, off = kr * a.Win + ks;
+            const unsigned m = (unsigned)(vmask >> (tap * NX));
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int iy = xiy0[i] + kr, ix = xix0[i] + ks;
-            const bool ok = xn[i] >= 0 && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
-            pix[i] = ok ? (xn[i] * a.Hin + (iy >> ush)) * a.Win + (ix >> ush) : -1;
+            for (int i = 0; i < NX; ++i) pix[i] = ((m >> i) & 1u) ? pbase[i] + off : -1;
+        } else {
+            const int kr = tap / a.R, ks = tap - kr * a.R;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int iy = xiy0[i] + kr, ix = xix0[i] + ks;
+                const bool ok = xn[i] >= 0 && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+                pix[i] = ok ? (xn[i] * a.Hin + (iy >> ush)) * a.Win + (ix >> ush) : -1;
+            }
         }
     };
     const int slice = SPLIT ? blockIdx.y : 0;
@@ -773,20 +800,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm16_kernel(const ConvArg
         }
     };
     auto advance = [&]() {
-        ++kt_n;
-        if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
+        if constexpr (KORD) {
+            if (++tap_n == 9) { tap_n = 0; ++cc_n; }
+            kt_n = tap_n * a.CT + cc_n;
+        } else {
+            ++kt_n;
+            if (++cc_n == a.CT) { cc_n = 0; ++tap_n; }
+        }
     };
     const int swz = (p16 >> 1) & 7;
     const int xrow_off = (wm * 32 * TJ + p16) * RB, wrow_off = (wn * 32 * TI + p16) * RB;
     static_assert(NS >= 2 && NL * (NS - 2) <= 63, "vmcnt is a 6-bit counter");
     auto start_tile = [&](int vb) {
         setup_tile(vb);
-        tap_n = kt_lo / a.CT; cc_n = kt_lo - tap_n * a.CT; kt_n = kt_lo;
+        if constexpr (KORD) { cc_n = kt_lo / 9; tap_n = kt_lo - cc_n * 9; kt_n = tap_n * a.CT + cc_n; }
+        else { tap_n = kt_lo / a.CT; cc_n = kt_lo - tap_n * a.CT; kt_n = kt_lo; }
         set_tap(tap_n);
 #pragma unroll
         for (int pp = 0; pp < NS - 1; ++pp) {
             if (pp < KTl) {
-                if (pp > 0 && cc_n == 0) set_tap(tap_n);
+                if (pp > 0 && (KORD || cc_n == 0)) set_tap(tap_n);
                 issue_slice(pp, 0, NL);
                 advance();
             }
@@ -842,7 +875,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm16_kernel(const ConvArg
         const bool more = kt + NS - 1 < KTl;
         const char* xb = smem + s * STAGE;
         const char* wb = xb + BM * RB;
-        if (more && cc_n == 0) set_tap(tap_n);
+        if (more && (KORD || cc_n == 0)) set_tap(tap_n);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {  // two 32-deep MFMA k-steps per 64-deep stage
             const int co = ((4 * ks + g) ^ swz) << 4;
@@ -1452,13 +1485,13 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     return CCNET_OK;
 }
 
-template <int WM, int WN, int TJ, int TI, int NS = 2, bool SPLIT = false, bool PERSIST = false>
+template <int WM, int WN, int TJ, int TI, int NS = 2, bool SPLIT = false, bool PERSIST = false, bool KORD = false>
 int launch16(const ConvArgs& a, int batch, hipStream_t st) {
     constexpr int BM = 32 * TJ * WM, BN = 32 * TI * WN, NT = 64 * WM * WN, BK = 64;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv_gemm16_kernel<WM, WN, TJ, TI, NS, SPLIT, PERSIST>,
+        if (hipFuncSetAttribute((const void*)conv_gemm16_kernel<WM, WN, TJ, TI, NS, SPLIT, PERSIST, KORD>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return CCNET_ELAUNCH;
         attr_set.store(true, std::memory_order_release);
@@ -1473,8 +1506,12 @@ int launch16(const ConvArgs& a, int batch, hipStream_t st) {
         b.winM = 32 / b.winN;
         b.mfast = ((b.tilesM % b.winM) == 0 && (b.tiles % 256) == 0) ? 2 : 0;
     }
+    // split-K 3x3 layers of the 8x8 level (<= 8 pixel panels): M-fastest, so that an XCD streams its share of the weights instead of
+    // all of them (the layer is weight-bound): 318 -> 207 MB per launch across the L2 boundary, -2 % time (profiles/r03_korder.txt)
+    // (and the 16x16-level ones where they run the channel-major K walk, see conv_gemm_impl)
+    if (SPLIT && g_order < 0 && a.R == 3 && (b.tilesM <= 8 || KORD)) b.mfast = 1;
     const int grid = PERSIST && g_persist && b.KT * BK <= (g_persist > 1 ? g_persist : 640) && b.tiles > kNumCUs ? kNumCUs : b.tiles;
-    hipLaunchKernelGGL((conv_gemm16_kernel<WM, WN, TJ, TI, NS, SPLIT, PERSIST>), dim3(grid, SPLIT ? b.splitk : 1, batch), dim3(NT), LDS, st, b);
+    hipLaunchKernelGGL((conv_gemm16_kernel<WM, WN, TJ, TI, NS, SPLIT, PERSIST, KORD>), dim3(grid, SPLIT ? b.splitk : 1, batch), dim3(NT), LDS, st, b);
     CCNET_LAUNCH_CHECK();
     if (SPLIT && !b.out32) {
         const long long items = (long long)b.M * (b.Cout / 8);
@@ -1524,17 +1561,19 @@ const TileCfg kCfgs[] = {
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // The v_mfma_f32_16x16x32_bf16 instances of the plain / split-K launches of a tile configuration (same tiles, stages and waves;
 // conv_gemm16_kernel).  GEGLU, row-statistics and residual-prefetch launches, and the 32-deep-stage configurations, have none.
-struct Cfg16 { int cfg; LaunchFn fn, fn_split; };
+// fn_k / fn_split_k: the channel-major K walk (KORD) of a 3x3 convolution without upsampling, where the instance exists
+struct Cfg16 { int cfg; LaunchFn fn, fn_split, fn_k = nullptr, fn_split_k = nullptr; };
 const Cfg16 kCfg16[] = {
     {0, launch16<2, 2, 2, 2>, nullptr},
     {3, launch16<2, 2, 2, 5>, launch16<2, 2, 2, 5, 2, true>},
-    {10, launch16<4, 2, 2, 4>, nullptr},
+    {10, launch16<4, 2, 2, 4>, nullptr, launch16<4, 2, 2, 4, 2, false, false, true>},
     {13, launch16<2, 2, 2, 2, 3>, nullptr},
-    {15, launch16<4, 2, 2, 2, 3>, launch16<4, 2, 2, 2, 3, true>},
+    {15, launch16<4, 2, 2, 2, 3>, launch16<4, 2, 2, 2, 3, true>, launch16<4, 2, 2, 2, 3, false, false, true>, launch16<4, 2, 2, 2, 3, true, false, true>},
     {19, launch16<4, 2, 1, 2, 3>, launch16<4, 2, 1, 2, 3, true>},
-    {23, launch16<4, 2, 2, 5, 2, false, true>, launch16<4, 2, 2, 5, 2, true>},
+    {23, launch16<4, 2, 2, 5, 2, false, true>, launch16<4, 2, 2, 5, 2, true>, launch16<4, 2, 2, 5, 2, false, true, true>, launch16<4, 2, 2, 5, 2, true, false, true>},
     {29, launch16<4, 2, 1, 5>, nullptr},
 };
+int g_korder = -1;  // tuning (ccnet_set_option key 10): K walk of R > 1 convolutions, 0 = (tap, channel chunk), 1 = (channel chunk, tap), -1 = per layer
 int g_m16 = 1;  // tuning (ccnet_set_option key 9): 0 = every launch on the 32x32x16 kernel
 
 // 256 pixels x 32 couts, 4 waves, two blocks per CU: the output convolutions (Cout <= 8); raw-accumulator epilogue
@@ -1632,6 +1671,7 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 7) { g_attn_mode = value; return CCNET_OK; }
     if (key == 8) { g_pw320 = value; return CCNET_OK; }
     if (key == 9) { g_m16 = value; return CCNET_OK; }
+    if (key == 10) { g_korder = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 
@@ -1843,6 +1883,12 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
         a.ws = (float*)ws;
     }
     const TileCfg& cfg = kCfgs[cfg_i];
+    // channel-major K walk for the 3x3 convolutions on 256 x 320 tiles (profiles/r03_korder.txt): unsplit (the 64x64 / 32x32 levels)
+    // -3 % time at 64x64, -1 % at 32x32 and 4 - 6 x fewer bytes across the L2 boundary; split along K (the 16x16 level) together
+    // with the M-fastest tile walk, which alone would double the traffic (an XCD then holds 16 pixel panels, and only under this
+    // walk do their tap re-reads hit L2): 459 -> 161 MB per launch, time within 1 %.  The 8x8-level layers (256 x 128 tiles) are
+    // weight-bound and lose 6 % under it (a weight row is then read in 128-byte pieces nine chunks apart): (tap, channel) walk.
+    a.korder = (p->R == 3 && p->ups == 1 && (g_korder > 0 || (g_korder < 0 && cfg_i == 23))) ? 1 : 0;
     // row statistics come from the K-loop kernel's epilogue: only unsplit plans on the tiles that have the instance
     if (p->stat_out && (a.splitk > 1 || !cfg.fn_stat || (p->Cout % cfg.stat_span))) {
         if (rec) --g_prof_used;  // (nothing was launched: drop the half-made profiling record)
@@ -1851,7 +1897,11 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
     LaunchFn fn = a.splitk > 1 ? cfg.fn_split : geglu ? cfg.fn_geglu : p->stat_out ? cfg.fn_stat : cfg.fn;
     if (g_m16 && !geglu && !p->stat_out && !p->rowstat) {
         for (const Cfg16& c : kCfg16)
-            if (c.cfg == cfg_i && (a.splitk > 1 ? c.fn_split : c.fn)) fn = a.splitk > 1 ? c.fn_split : c.fn;
+            if (c.cfg == cfg_i && (a.splitk > 1 ? c.fn_split : c.fn)) {
+                fn = a.splitk > 1 ? c.fn_split : c.fn;
+                const LaunchFn fk = a.splitk > 1 ? c.fn_split_k : c.fn_k;
+                if (a.korder && fk) fn = fk;
+            }
     }
     const int rc = fn(a, batch, st);
     if (rec) (void)hipEventRecord(rec->e1, st);
