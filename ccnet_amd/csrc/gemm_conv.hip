@@ -1562,7 +1562,10 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // The v_mfma_f32_16x16x32_bf16 instances of the plain / split-K launches of a tile configuration (same tiles, stages and waves;
 // conv_gemm16_kernel).  GEGLU, row-statistics and residual-prefetch launches, and the 32-deep-stage configurations, have none.
 // fn_k / fn_split_k: the channel-major K walk (KORD) of a 3x3 convolution without upsampling, where the instance exists
-struct Cfg16 { int cfg; LaunchFn fn, fn_split, fn_k = nullptr, fn_split_k = nullptr; };
+// fn_np: the instance without the persistent tile loop, for launches that would run one tile per block anyway (K > 640): the
+// next-tile state of the persistent instance costs the 256 x 320 tile its fragment prefetch (256 registers: hipcc then reads
+// each cout fragment of the second MFMA k-step right before its four MFMAs)
+struct Cfg16 { int cfg; LaunchFn fn, fn_split, fn_k = nullptr, fn_split_k = nullptr, fn_np = nullptr; };
 const Cfg16 kCfg16[] = {
     {0, launch16<2, 2, 2, 2>, nullptr},
     {3, launch16<2, 2, 2, 5>, launch16<2, 2, 2, 5, 2, true>},
@@ -1570,7 +1573,8 @@ const Cfg16 kCfg16[] = {
     {13, launch16<2, 2, 2, 2, 3>, nullptr},
     {15, launch16<4, 2, 2, 2, 3>, launch16<4, 2, 2, 2, 3, true>, launch16<4, 2, 2, 2, 3, false, false, true>, launch16<4, 2, 2, 2, 3, true, false, true>},
     {19, launch16<4, 2, 1, 2, 3>, launch16<4, 2, 1, 2, 3, true>},
-    {23, launch16<4, 2, 2, 5, 2, false, true>, launch16<4, 2, 2, 5, 2, true>, launch16<4, 2, 2, 5, 2, false, true, true>, launch16<4, 2, 2, 5, 2, true, false, true>},
+    {23, launch16<4, 2, 2, 5, 2, false, true>, launch16<4, 2, 2, 5, 2, true>, launch16<4, 2, 2, 5, 2, false, false, true>, launch16<4, 2, 2, 5, 2, true, false, true>,
+     launch16<4, 2, 2, 5, 2, false, false>},
     {29, launch16<4, 2, 1, 5>, nullptr},
 };
 int g_korder = -1;  // tuning (ccnet_set_option key 10): K walk of R > 1 convolutions, 0 = (tap, channel chunk), 1 = (channel chunk, tap), -1 = per layer
@@ -1900,6 +1904,7 @@ int conv_gemm_impl(const ccnet_conv_params* p, void* ws, int64_t ws_bytes, int w
             if (c.cfg == cfg_i && (a.splitk > 1 ? c.fn_split : c.fn)) {
                 fn = a.splitk > 1 ? c.fn_split : c.fn;
                 const LaunchFn fk = a.splitk > 1 ? c.fn_split_k : c.fn_k;
+                if (a.splitk == 1 && c.fn_np && !(g_persist && a.KT * 64 <= (g_persist > 1 ? g_persist : 640))) fn = c.fn_np;
                 if (a.korder && fk) fn = fk;
             }
     }
