@@ -1330,11 +1330,29 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
         }
         f32x16 acc = bq;
         if constexpr (LNF) acc = f32x16{};  // (the bias joins after the normalisation)
+        if constexpr (C == 640 && !(PW_DIAG & 2)) {
+            // 160 weight registers leave hipcc no room it would use for a read-ahead by itself: it reads each row fragment right
+            // before its MFMA, and two waves per SIMD do not cover an LDS round trip per MFMA.  Pinned order: the fragment of
+            // k-step ks + PF is read in the slot of MFMA ks.
+            constexpr int PF = 4;
+            bf16x8 xq[PF];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 xf = *(const bf16x8*)(xb + (((2 * ks) << 4) ^ xsw));
-            if constexpr (PW_DIAG & 2) acc[ks & 15] += __builtin_bit_cast(f32x4, xf)[ks & 3];
-            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+            for (int i = 0; i < PF; ++i) xq[i] = *(const bf16x8*)(xb + (((2 * i) << 4) ^ xsw));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xf = xq[ks % PF];
+                if (ks + PF < KS) xq[ks % PF] = *(const bf16x8*)(xb + (((2 * (ks + PF)) << 4) ^ xsw));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 xf = *(const bf16x8*)(xb + (((2 * ks) << 4) ^ xsw));
+                if constexpr (PW_DIAG & 2) acc[ks & 15] += __builtin_bit_cast(f32x4, xf)[ks & 3];
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+            }
         }
         constexpr int ST = (PW_DIAG & 1) ? 0 : GEGLU ? 1 : 2, PER = (RES ? 2 : 0) + PPW + ST;
         if constexpr (LNF) {
