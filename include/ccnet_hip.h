@@ -286,8 +286,10 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t*
  * 6 the one-pass GroupNorm paths, 7 the attention instance (0 by shape, 1 round-1 kernel, 2 long-key instance wherever it
  * applies), 8 the streaming pointwise kernel (0 off; bits: 1 on, 2 several cout groups, 4 GEGLU, 8 the 640-channel instance, 16 LayerNorm
  * statistics in the kernel: without it a colsum-only problem returns CCNET_EUNSUP), 9 the 16x16x32-MFMA instances of the tile
- * kernel (0: every launch on the 32x32x16 instances), 2 = 2 also selects the windowed tile walk.  Results do not depend on
- * any of them beyond the order of fp32 sums inside a tile (the streaming kernel is bit-identical to the tiled one). */
+ * kernel (0: every launch on the 32x32x16 instances), 2 = 2 also selects the windowed tile walk, 10 the K walk of the 3x3
+ * convolutions on those instances (0 (tap, channel chunk), 1 (channel chunk, tap), -1 per layer: the walk changes, the weight
+ * image does not).  Results do not depend on any of them beyond the order of fp32 sums inside a tile (the streaming kernel is
+ * bit-identical to the tiled one). */
 int ccnet_set_option(int key, int value);
 int ccnet_prof_enable(int on);
 int ccnet_prof_collect(double* ms, double* flops, int64_t* launches);
