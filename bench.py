@@ -96,8 +96,11 @@ def conv_algorithmic_bytes(M, Cout, K, R, flags):
     """Bytes one conv / linear launch has to move if every operand crosses HBM exactly once: the input pixels (not the
     im2col view), the weights, the output and the residual operands.  `flags` as in ccnet_prof_shapes: bit0 stride 2, bit1
     nearest x2 upsample in the gather, bit3 GEGLU epilogue (output half as wide), bit4 res1, bit5 res2 + out2, bit7 the fused
-    feed-forward block (recorded as M x C x 12 C: linear1 C -> 8C and linear2 4C -> C)."""
+    feed-forward block (recorded as M x C x 12 C: linear1 C -> 8C and linear2 4C -> C), bit8 the fused cross-attention branch."""
     fl = int(flags)
+    if fl & 256:  # fused cross-attention branch (ccnet_xattn_fused_bf16, recorded as M x C x (2 C + 2 keys)): rows in (also the
+        # residual), to_q + to_out weights, rows out (the prompt's K / V images: 100 KB per image, not counted)
+        return 2.0 * (M * Cout + 2 * Cout * Cout + M * Cout)
     if fl & 128:  # fused feed-forward block (ccnet_ff_geglu_fused_bf16): rows in (also the residual), both weight matrices, rows out
         return 2.0 * (M * Cout + Cout * K + M * Cout)
     cin = K / (R * R)
@@ -119,7 +122,7 @@ def hbm_traffic_per_launch():
     import csv
     n = f = w = rf = rw = 0.0
     for row in csv.reader(l for l in open(files[-1]) if not l.startswith("#")):
-        if len(row) == 5 and row[0].startswith(("conv_gemm_kernel<", "conv_gemm16_kernel<", "pw_stream_kernel<", "ff320_kernel")):
+        if len(row) == 5 and row[0].startswith(("conv_gemm_kernel<", "conv_gemm16_kernel<", "pw_stream_kernel<", "ff320_kernel", "xattn320_kernel")):
             n += float(row[1]); f += float(row[2]); w += float(row[3])
         if len(row) == 5 and row[0].startswith("splitk_reduce_kernel"):  # the second launch of a split-K call: its bytes, not a call of its own
             rf += float(row[2]); rw += float(row[3])
@@ -302,7 +305,7 @@ def main():
         traffic = hbm_traffic_per_launch()
         alg_per_launch = alg_bytes / max(launches, 1)
         tb = (traffic or {}).get("bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "conv / linear launches: conv_gemm16_kernel / conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA 16x16x32 / 32x32x16) + pw_stream_kernel (its streaming instance for the K = 320 / 640 pointwise layers) + ff320_kernel (fused LayerNorm -> linear1 -> GEGLU -> linear2 -> + x of the 320-channel level)",
+        roof = {"bound": "mfma", "kernel": "conv / linear launches: conv_gemm16_kernel / conv_gemm_kernel (implicit-GEMM conv/linear, bf16 MFMA 16x16x32 / 32x32x16) + pw_stream_kernel (its streaming instance for the K = 320 / 640 pointwise layers) + ff320_kernel / xattn320_kernel (fused LayerNorm -> linear1 -> GEGLU -> linear2 -> + x and fused LayerNorm -> to_q -> 77-key attention -> to_out -> + x of the 320-channel level)",
                 "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tb,
                 "traffic_unit": "bytes per launch crossing the L2 -> fabric boundary (HBM + Infinity Cache), PMC passes "

@@ -1,0 +1,407 @@
+// Fused cross-attention branch of a BasicTransformerBlock at 320 channels / 5 heads of 64 (the 64x64 level of the SD-2.1 geometry):
+//     out = x + to_out( softmax( to_q(LayerNorm(x)) K^T / sqrt(64) ) V )          (norm2 + attn2 + residual)
+// in ONE kernel, K / V being the prompt's hoisted projections (<= 80 keys per image).  Unfused it is three launches (LayerNorm-folded
+// to_q, 77-key attention, to_out + residual) that write and re-read the query and the attention output (84 MB each per call at
+// CFG batch 32).
+//
+// Shape of the work on a CU -- the fused feed-forward kernel's (fused_ff.hip): one workgroup of four waves, ONE wave per SIMD, a
+// wave owns 32 token rows for the whole block.  Per 128-row tile:
+//   1. LayerNorm of the wave's rows -> bf16, the B operand of to_q (80 registers);
+//   2. to_q in 10 blocks of 32 outputs (20 MFMAs 32x32x16 each, K = 320).  The rows of Wq are permuted at pack time so that a
+//      block's accumulators, rounded to bf16 in register order, ARE the B operand of the score MFMAs (k = head dim in natural
+//      order); the softmax scale and the log2 e of the kernel's exp2 are folded into Wq before its rounding to bf16;
+//   3. per head: scores^T = K_h q_h (3 key blocks x 4 k-steps; K sits in LDS row-major with the tile kernels' 16-byte-unit
+//      swizzle), softmax over the <= 80 keys in registers (a token's keys live in one lane pair: two cross-lane exchanges),
+//      P rounded to bf16 in register order is the B operand of O^T = V^T P (5 k-steps of 16 keys x 2 dim blocks; V^T sits in LDS
+//      with its keys permuted to that order), O / rowsum rounded to bf16 is the B operand of to_out for the head's 64 columns
+//      (40 MFMAs; Wo's columns permuted to the order in which a lane holds them), accumulated over the heads in 160 registers;
+//   4. + bias + the raw rows (re-read: L2 / Infinity Cache) -> store.
+// The weights stream through LDS by LDS-DMA in 20 stages of 20 KB per tile (10 Wq blocks, then per head two halves of its Wo
+// columns), packed on the host in exactly that order (ccnet_amd.ops.xattn_pack); the image's K / V^T (100 KB, built once per
+// prompt batch by ccnet_amd.ops.xattn_kv_image) stay resident while the workgroup walks consecutive tiles of that image.
+#include "common.h"
+#include <atomic>
+#include <type_traits>
+
+namespace {
+
+struct XaArgs {
+    const __bf16* x; const __bf16* wp; const float* bq; const float* bo; const float* gamma; const float* beta;
+    const __bf16* kv; __bf16* out;
+    int M, ldx, ldo, tiles, tpb, HW, S;
+    float eps;
+    unsigned wp_bytes, kv_bytes;
+};
+
+constexpr int XA_C = 320, XA_KS = XA_C / 16, XA_HEADS = 5, XA_KEYS = 80;
+constexpr int XA_KB = XA_KEYS * XA_C * 2;                 // K image: [80 keys][320] bf16, 16-byte units swizzled per row
+constexpr int XA_VB = (XA_KEYS / 16) * 2 * XA_C * 16;     // V^T image: [5 k-steps][2 hh][320 dims][8 keys] bf16
+constexpr int XA_KVB = XA_KB + XA_VB;                     // 102400
+constexpr int XA_STAGEB = 32 * XA_C * 2;                  // 20480: one Wq block, or two k-steps of a head's Wo image
+constexpr int XA_NSTAGE = XA_C / 32 + 2 * XA_HEADS;       // 20 stages per tile
+constexpr int XA_NS = 2;
+constexpr int XA_PPW = XA_STAGEB / 1024 / 4;              // 1-KiB DMA pieces per wave and stage (5)
+constexpr int XA_KVPPW = XA_KVB / 1024 / 4;               // ... per wave for the K / V^T images (25)
+constexpr int XA_TAB = 4 * XA_C * 4;                      // gamma | beta | bq | bo (fp32)
+constexpr int XA_LDS = XA_KVB + XA_NS * XA_STAGEB + XA_TAB;
+constexpr int XA_PF = 4;                                  // weight fragments are read this many MFMA slots ahead of their use
+#ifndef XA_DIAG
+#define XA_DIAG 0  // timing experiments (never the shipped library): bit 0 no weight DMA in the steady state, bit 1 no softmax arithmetic, bit 2 no wait / barrier per stage, bit 3 no LayerNorm arithmetic and no residual, bit 4 no score / P.V MFMAs
+#endif
+static_assert(XA_STAGEB % 4096 == 0 && XA_KVB % 4096 == 0, "stages and images divide into whole pieces per wave");
+
+__global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    char* ring = smem + XA_KVB;
+    float* gms = (float*)(ring + XA_NS * XA_STAGEB);
+    float* bts = gms + XA_C;
+    float* bqs = bts + XA_C;
+    float* bos = bqs + XA_C;
+    for (int t = tid; t < XA_C; t += 256) {
+        gms[t] = a.gamma[t]; bts[t] = a.beta[t]; bqs[t] = a.bq ? a.bq[t] : 0.f; bos[t] = a.bo ? a.bo[t] : 0.f;
+    }
+    const int t_lo = (int)blockIdx.x * a.tpb;
+    const int t_hi = min(t_lo + a.tpb, a.tiles);
+    if (t_lo >= t_hi) return;  // (whole workgroup: no barrier is pending)
+    const int total_loads = (t_hi - t_lo) * XA_NSTAGE;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, a.wp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void*)a.kv, 0, a.kv_bytes, 0x00020000);
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, unsigned off) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, (int)off, 0, 0, 0);
+    };
+    {   // stage 0 of the weight stream
+        char* base = ring + wave * (XA_PPW * 1024);
+        const unsigned off = (unsigned)wave * (XA_PPW * 1024) + (unsigned)lane * 16u;
+#pragma unroll
+        for (int i = 0; i < XA_PPW; ++i) dma(rw, base + i * 1024, off + i * 1024);
+    }
+
+    // row-major 640-byte rows with the unit swizzle (Wq blocks and the K image): fragment of k-step ks = 4 m + r of row l31 is
+    // the 16-byte unit 8 m + ((2 r) ^ (hh ^ swz(l31)))
+    const int c8 = hh ^ ((l31 >> 1) & 7);
+    int w1off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w1off[r] = l31 * (XA_C * 2) + (((2 * r) ^ c8) << 4);
+    const int w2off = hh * (XA_C * 16) + l31 * 16;  // [hh][320][8] images (Wo k-steps, V^T k-steps)
+
+    auto swap32 = [](unsigned& lo, unsigned& hi) {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
+    };
+
+    int gs = 0, cur_img = -1;
+    // a tile's raw rows are requested one tile ahead (during the previous tile's heads, when the registers of its normalised
+    // rows are free): their HBM latency hides behind that tile's MFMAs
+    u32x4 xr[XA_KS];
+    auto request_rows = [&](int tile) {
+        const int r = tile * 128 + wave * 32 + l31;
+        const __bf16* p = a.x + (long long)(r < a.M ? r : a.M - 1) * a.ldx + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < XA_KS; ++ks) xr[ks] = *(const u32x4*)(p + 16 * ks);
+    };
+    request_rows(t_lo);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int row = tile * 128 + wave * 32 + l31;
+        const bool rok = row < a.M;
+        const __bf16* xp = a.x + (long long)(rok ? row : a.M - 1) * a.ldx + 8 * hh;
+        // ---- the image's K / V^T (wave-uniform test; a tile lies inside one image: HW % 128 == 0)
+        const int img = (tile * 128) / a.HW;
+        if (img != cur_img) {
+            if (cur_img >= 0) {  // every wave has left the previous image's tiles
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            char* base = smem + wave * (XA_KVPPW * 1024);
+            unsigned l16 = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(l16));  // (computed here: hoisted out of the tile loop it would cost a register for the whole kernel)
+            const unsigned off = (unsigned)img * XA_KVB + (unsigned)wave * (XA_KVPPW * 1024) + l16;
+#pragma unroll
+            for (int i = 0; i < XA_KVPPW; ++i) dma(rkv, base + i * 1024, off + i * 1024);
+            cur_img = img;  // (landed by the next stage head: it waits for vmcnt(0) and meets the barrier)
+        }
+        // ---- the wave's 32 rows -> LayerNorm -> bf16 (two-pass statistics over the lane's 160 values + its lane ^ 32 partner's)
+        bf16x8 xh[XA_KS];
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < XA_KS; ++ks) {
+                float f[8];
+                unpack8(xr[ks], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[e];
+            }
+            s += __shfl_xor(s, 32);
+            const float mean = s * (1.0f / XA_C);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < XA_KS; ++ks) {
+                float f[8];
+                unpack8(xr[ks], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q = fmaf(d, d, q); }
+            }
+            q += __shfl_xor(q, 32);
+            const float rstd = rsqrtf(q * (1.0f / XA_C) + a.eps);
+            if (tile == t_lo) {  // the tables written above
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll
+            for (int ks = 0; ks < XA_KS; ++ks) {
+                float f[8], o[8];
+                unpack8(xr[ks], f);
+                const f32x4 g0 = *(const f32x4*)(gms + 16 * ks + 8 * hh), g1 = *(const f32x4*)(gms + 16 * ks + 8 * hh + 4);
+                const f32x4 t0 = *(const f32x4*)(bts + 16 * ks + 8 * hh), t1 = *(const f32x4*)(bts + 16 * ks + 8 * hh + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (f[e] - mean) * rstd * g0[e] + t0[e];
+                    o[4 + e] = (f[4 + e] - mean) * rstd * g1[e] + t1[e];
+                }
+                xh[ks] = (XA_DIAG & 8) ? __builtin_bit_cast(bf16x8, xr[ks]) : __builtin_bit_cast(bf16x8, pack8(o));
+            }
+        }
+        // stage gs: wait until it has landed (this wave's pieces: vmcnt; the others': barrier; every wave has then also left stage
+        // gs - 1, whose slot takes stage gs + 1)
+        const char* sb; char* dma_base; unsigned dma_off;
+        auto stage_head = [&]() {
+            if (!(XA_DIAG & 4)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            asm volatile("" ::: "memory");
+            sb = ring + (gs % XA_NS) * XA_STAGEB;
+            const int gnext = gs + 1;
+            dma_base = ring + (gnext % XA_NS) * XA_STAGEB + wave * (XA_PPW * 1024);
+            dma_off = (unsigned)(gnext % XA_NSTAGE) * XA_STAGEB + (unsigned)wave * (XA_PPW * 1024) + (unsigned)lane * 16u;
+            dma_off |= gnext < total_loads ? 0u : 0x80000000u;  // beyond the last stage: outside the descriptor, zeros land
+            ++gs;
+        };
+
+        // ---- to_q: 10 blocks of 32 outputs -> the bf16 B operands of the score MFMAs, k-steps 2 i, 2 i + 1 of the 20
+        bf16x8 qf[XA_KS];
+#pragma unroll
+        for (int i = 0; i < XA_C / 32; ++i) {
+            stage_head();
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = *(const f32x4*)(bqs + 32 * i + 8 * q + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * q + e] = t[e];
+            }
+            bf16x8 fr[XA_KS];
+#pragma unroll
+            for (int k = 0; k < XA_PF; ++k) fr[k] = *(const bf16x8*)(sb + w1off[k & 3] + (k >> 2) * 128);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < XA_KS; ++k) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[k], xh[k], acc, 0, 0, 0);
+                if (k + XA_PF < XA_KS) fr[k + XA_PF] = *(const bf16x8*)(sb + w1off[(k + XA_PF) & 3] + ((k + XA_PF) >> 2) * 128);
+                if (k >= 1 && k <= XA_PPW && !(XA_DIAG & 1)) dma(rw, dma_base + (k - 1) * 1024, dma_off + (k - 1) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float lo8[8], hi8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lo8[e] = acc[e]; hi8[e] = acc[8 + e]; }
+            qf[2 * i] = __builtin_bit_cast(bf16x8, pack8(lo8));
+            qf[2 * i + 1] = __builtin_bit_cast(bf16x8, pack8(hi8));
+        }
+
+        // ---- the heads; the outputs of the wave's rows accumulate over them (start: to_out's bias)
+        f32x16 acc_o[XA_C / 32];
+#pragma unroll
+        for (int i = 0; i < XA_C / 32; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = *(const f32x4*)(bos + 32 * i + 8 * q + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc_o[i][4 * q + e] = t[e];
+            }
+        if (tile + 1 < t_hi) request_rows(tile + 1);
+#pragma unroll
+        for (int h = 0; h < XA_HEADS; ++h) {
+            // scores^T: key 32 kb + 8 q + 4 hh + e of token l31 in register 4 q + e of block kb (rows 80 .. 95 of block 2 read
+            // the V^T image behind the K image: finite garbage in rows that are masked below)
+            f32x16 sc[3];
+            bf16x8 kf[12], vf[10];
+            auto read_k = [&](int kb) {  // the four K fragments of key block kb (one block ahead of its MFMAs)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ks = 4 * h + s;
+                    kf[4 * kb + s] = *(const bf16x8*)(smem + kb * 32 * (XA_C * 2) + w1off[ks & 3] + (ks >> 2) * 128);
+                }
+            };
+            read_k(0);
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sc[kb][k] = 0.f;
+                if (kb + 1 < 3) read_k(kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ks = 4 * h + s;
+                    if (XA_DIAG & 16) sc[kb][s] += __builtin_bit_cast(f32x4, qf[ks])[s & 3];
+                    else sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4 * kb + s], qf[ks], sc[kb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // softmax over the keys (quads 2, 3 of block 2 are keys >= 80: never valid)
+            float m = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int q = 0; q < (kb < 2 ? 4 : 2); ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = 32 * kb + 8 * q + 4 * hh + e;
+                        const float v = key < a.S ? sc[kb][4 * q + e] : -INFINITY;
+                        sc[kb][4 * q + e] = v;
+                        m = fmaxf(m, v);
+                    }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+            bf16x8 pf[5];
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const int kb = ks >> 1, q0 = 2 * (ks & 1);
+                float p8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    p8[t] = (XA_DIAG & 2) ? sc[kb][4 * q0 + t] : __builtin_amdgcn_exp2f(sc[kb][4 * q0 + t] - m);
+                    l += p8[t];
+                }
+                pf[ks] = __builtin_bit_cast(bf16x8, pack8(p8));
+            }
+            l += __shfl_xor(l, 32);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks)
+                    vf[5 * db + ks] = *(const bf16x8*)(smem + XA_KB + ks * (2 * XA_C * 16) + w2off + (64 * h + 32 * db) * 16);
+            // O^T = V^T P: dims 64 h + 32 db + (8 q + 4 hh + e) of token l31
+            f32x16 ov[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ov[db][k] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) {
+                    if (XA_DIAG & 16) ov[db][ks] += __builtin_bit_cast(f32x4, pf[ks])[ks & 3];
+                    else ov[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[5 * db + ks], pf[ks], ov[db], 0, 0, 0);
+                }
+            }
+            const float inv = 1.0f / l;
+            bf16x8 of[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float o8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o8[t] = ov[s >> 1][8 * (s & 1) + t] * inv;
+                of[s] = __builtin_bit_cast(bf16x8, pack8(o8));
+            }
+            // to_out for the head's 64 columns: two stages of two k-steps
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                stage_head();
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 fr[2 * (XA_C / 32)];
+#pragma unroll
+                for (int k = 0; k < XA_PF; ++k) fr[k] = *(const bf16x8*)(sb + (k / 10) * (XA_C * 32) + w2off + (k % 10) * 512);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 2 * (XA_C / 32); ++k) {
+                    const int s2 = k / 10, i = k % 10;
+                    acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[k], of[2 * j + s2], acc_o[i], 0, 0, 0);
+                    if (k + XA_PF < 2 * (XA_C / 32)) {
+                        const int kk = k + XA_PF;
+                        fr[kk] = *(const bf16x8*)(sb + (kk / 10) * (XA_C * 32) + w2off + (kk % 10) * 512);
+                    }
+                    if (k >= 1 && k <= XA_PPW && !(XA_DIAG & 1)) dma(rw, dma_base + (k - 1) * 1024, dma_off + (k - 1) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- the tile's outputs leave.  After the permlane32 swap a lane owns couts 32 i + 16 p + 8 hh .. + 7 of its row; the
+        // residual is the raw 16-byte unit 2 i + p of the row (re-read), one 16-byte store each.
+        {
+            __bf16* orow = a.out + (long long)row * a.ldo + 8 * hh;
+            u32x4 rr[XA_C / 32][2];  // (one burst: the scores' and probabilities' registers are free by now)
+#pragma unroll
+            for (int i = 0; i < XA_C / 32; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) rr[i][p] = (XA_DIAG & 8) ? u32x4{0u, 0u, 0u, 0u} : *(const u32x4*)(xp + 32 * i + 16 * p);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < XA_C / 32; ++i) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float w8[8], r8[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned lo = __float_as_uint(acc_o[i][8 * p + e]), hi = __float_as_uint(acc_o[i][8 * p + 4 + e]);
+                        swap32(lo, hi);
+                        w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
+                    }
+                    unpack8(rr[i][p], r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w8[e] += r8[e];
+                    if (rok) *(u32x4*)(orow + 32 * i + 16 * p) = pack8(w8);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-fill DMAs of the closing stage: no LDS write outlives the workgroup)
+}
+
+}  // namespace
+
+extern "C" int ccnet_prof_open(double flops, int M, int Cout, int K, int R, int flags, void* stream);  // gemm_conv.hip
+extern "C" void ccnet_prof_close(int handle, void* stream);
+
+extern "C" int64_t ccnet_xattn_packed_bytes(int C, int heads) {
+    if (C != XA_C || heads != XA_HEADS) return 0;
+    return (int64_t)XA_NSTAGE * XA_STAGEB;
+}
+
+extern "C" int64_t ccnet_xattn_kv_image_bytes(int C, int heads) {
+    if (C != XA_C || heads != XA_HEADS) return 0;
+    return XA_KVB;
+}
+
+extern "C" int ccnet_xattn_fused_bf16(const ccnet_xattn_params* p, void* stream) {
+    if (!p || !p->x || !p->w_packed || !p->gamma || !p->beta || !p->kv_image || !p->out) return CCNET_EINVAL;
+    if (p->M <= 0 || (p->ldx % 8) || (p->ldo % 8) || p->ldx < p->C || p->ldo < p->C || p->images <= 0) return CCNET_EINVAL;
+    if (p->C != XA_C || p->heads != XA_HEADS || p->keys <= 0 || p->keys > XA_KEYS) return CCNET_EUNSUP;
+    if (p->rows_per_image <= 0 || (p->rows_per_image % 128) || (long long)p->rows_per_image * p->images < p->M) return CCNET_EUNSUP;
+    if ((long long)p->images * XA_KVB >= 0x7fffffffLL) return CCNET_EUNSUP;
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)xattn320_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS) != hipSuccess)
+            return CCNET_ELAUNCH;
+        attr_set.store(true, std::memory_order_release);
+    }
+    XaArgs a{};
+    a.x = (const __bf16*)p->x; a.wp = (const __bf16*)p->w_packed; a.bq = p->bq; a.bo = p->bo; a.gamma = p->gamma; a.beta = p->beta;
+    a.kv = (const __bf16*)p->kv_image; a.out = (__bf16*)p->out;
+    a.M = p->M; a.ldx = p->ldx; a.ldo = p->ldo; a.HW = p->rows_per_image; a.S = p->keys; a.eps = p->eps;
+    a.tiles = (p->M + 127) / 128;
+    // consecutive tiles per workgroup (they share the image's K / V^T), one round of the chip
+    a.tpb = (a.tiles + 255) / 256;
+    const int grid = (a.tiles + a.tpb - 1) / a.tpb;
+    a.wp_bytes = (unsigned)(XA_NSTAGE * XA_STAGEB);
+    a.kv_bytes = (unsigned)((long long)p->images * XA_KVB);
+    // benchmark hook (ccnet_prof_enable): recorded as an M x C x (2 C + 2 keys) product (to_q + scores + P.V + to_out), flag bit 8
+    const int rec = ccnet_prof_open(2.0 * p->M * (double)XA_C * (2.0 * XA_C + 2.0 * p->keys), p->M, XA_C, 2 * XA_C + 2 * p->keys, 1, 256, stream);
+    hipLaunchKernelGGL(xattn320_kernel, dim3(grid), dim3(256), XA_LDS, (hipStream_t)stream, a);
+    const bool ok = hipGetLastError() == hipSuccess;
+    ccnet_prof_close(rec, stream);
+    if (!ok) return CCNET_ELAUNCH;
+    return CCNET_OK;
+}

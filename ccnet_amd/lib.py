@@ -28,6 +28,7 @@ EXPORTS = [
     "ccnet_layernorm_bwd_bf16", "ccnet_softmax_bwd_rows_bf16", "ccnet_geglu_bwd_bf16", "ccnet_silu_bf16", "ccnet_axpby_bf16",
     "ccnet_resample_bwd_bf16", "ccnet_attention_d64_lse_bf16", "ccnet_attention_d64_bwd_bf16",
     "ccnet_attention_d64_prescaled_bf16", "ccnet_ff_geglu_fused_bf16", "ccnet_ff_packed_bytes", "ccnet_noalloc_init",
+    "ccnet_xattn_fused_bf16", "ccnet_xattn_packed_bytes", "ccnet_xattn_kv_image_bytes",
 ]
 
 
@@ -123,6 +124,11 @@ def load() -> C.CDLL:
     lib.ccnet_ff_geglu_fused_bf16.argtypes = [vp, vp]
     lib.ccnet_ff_packed_bytes.argtypes = [i, i]
     lib.ccnet_ff_packed_bytes.restype = C.c_int64
+    lib.ccnet_xattn_fused_bf16.argtypes = [vp, vp]
+    lib.ccnet_xattn_packed_bytes.argtypes = [i, i]
+    lib.ccnet_xattn_packed_bytes.restype = C.c_int64
+    lib.ccnet_xattn_kv_image_bytes.argtypes = [i, i]
+    lib.ccnet_xattn_kv_image_bytes.restype = C.c_int64
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default

@@ -53,6 +53,10 @@ FF_FUSED = os.environ.get("CCNET_FF_FUSED", "1") == "1"
 # query are evaluated once, on B rows, and duplicated there (a sampler asks for it with `_cfg_shared`).  0: A/B, both halves
 # evaluated from the start.
 CFG_SHARE = os.environ.get("CCNET_CFG_SHARE", "1") == "1"
+# CCNET_XATTN_FUSED=1 (default): norm2 -> attn2.to_q -> cross-attention -> attn2.to_out -> + x of the 320-channel level run as ONE
+# launch (ccnet_xattn_fused_bf16: neither the query nor the attention output reaches HBM) where the rows fill the chip; the
+# prompt's K / V are laid out for it once per prompt batch (context_kv).  CCNET_XATTN_FUSED=0: A/B.
+XATTN_FUSED = os.environ.get("CCNET_XATTN_FUSED", "1") == "1"
 FF_FUSED_MIN_ROWS = 32768  # 128-row tiles, one workgroup per CU: below 256 tiles the three launches are faster
 
 
@@ -292,8 +296,12 @@ class _Trunk(nn.Module):
             if FF_FUSED and not LN_FOLD:
                 ffp = ops.ff_pack(b.ff.linear1.weight.detach().to(dev), b.ff.linear1.bias.detach().to(dev),
                                   b.ff.linear2.weight.detach().to(dev))  # None: width not covered by the fused kernel
+            xap = None
+            if XATTN_FUSED and not LN_FOLD and a.head_ch == 64 and b.attn2.to_q.bias is None:
+                xap = ops.xattn_pack(b.attn2.to_q.weight.detach().to(dev), None, b.attn2.to_out[0].weight.detach().to(dev),
+                                     a.heads)  # None: width not covered by the fused kernel
             return {
-                "ffp": ffp,
+                "ffp": ffp, "xap": xap,
                 "qkv1i": i_qkv, "q2i": i_q2,
                 "qkv1f": f_qkv, "q2f": f_q2, "ff1f": f_ff1,
                 "norm": (f32(a.norm.weight), f32(a.norm.bias)), "pin": pconv(a.proj_in.conv),
@@ -432,7 +440,10 @@ class _Trunk(nn.Module):
         out = []
         for a in pk["att_order"]:
             p = pk["att"][id(a)]
-            out.append(ops.linear(ctx, p["kv2"], None, 2 * p["inner"], ctx.shape[1]))
+            kv = ops.linear(ctx, p["kv2"], None, 2 * p["inner"], ctx.shape[1])
+            if p["xap"] is not None:  # the same keys / values as the LDS images of the fused cross-attention kernel
+                kv._ximg = ops.xattn_kv_image(kv, kv.shape[0] // S, S, p["inner"])
+            out.append(kv)
         return out, S
 
     def _run_resnet(self, pk, r, x: Act, tall, x2: Optional[Act] = None, res2: Optional[Act] = None):
@@ -503,16 +514,36 @@ class _Trunk(nn.Module):
                 qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1s"] if pre else p["qkv1"], None, 3 * inner, inner)
             o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
             t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
+            ximg = getattr(kv, "_ximg", None) if p["xap"] is not None else None
+            xa = ximg is not None and T % 128 == 0 and t.shape[0] >= FF_FUSED_MIN_ROWS and (dup_to is None or hc == 64)
             q = None
-            if inl:
+            if xa:
+                # norm2 -> to_q -> cross-attention -> to_out -> + t in one launch; with shared CFG halves once per half (the same B
+                # query / residual rows, that half's keys and values) into the halves of one tensor
+                try:
+                    if dup_to is not None:
+                        t2 = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
+                        for hf in (0, 1):
+                            ops.xattn_fused(t, inner, heads, p["xap"], p["o2"][1], p["ln2"][0], p["ln2"][1], ximg[hf * B:(hf + 1) * B],
+                                            S, T, out=t2[hf * B * T:(hf + 1) * B * T])
+                        t, halves = t2, x
+                    else:
+                        t = ops.xattn_fused(t, inner, heads, p["xap"], p["o2"][1], p["ln2"][0], p["ln2"][1], ximg, S, T)
+                except CcnetUnsupported:
+                    xa = False
+            if not xa and inl:
                 w, b, cs = p["q2i"]
                 try:
                     q = ops.linear(t, w, b, inner, inner, colsum=cs)
                 except CcnetUnsupported:
                     pass
-            if q is None:
+            if xa:
+                pass
+            elif q is None:
                 q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
-            if dup_to is not None and hc == 64:
+            if xa:
+                pass
+            elif dup_to is not None and hc == 64:
                 # From here on the two halves differ (their prompts do).  Nothing is copied: the cross-attention and its output
                 # projection run once per half -- the same B query / residual rows, that half's keys and values -- into the
                 # two halves of one tensor, and so does proj_out below.

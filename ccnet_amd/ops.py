@@ -7,6 +7,7 @@ tensor [N*H*W, C] (NHWC, "pixel rows") plus its geometry.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -251,6 +252,81 @@ def ff_fused(x2d: torch.Tensor, Cc: int, pack, b2: torch.Tensor, gamma: torch.Te
     p.gamma = gamma.data_ptr(); p.beta = beta.data_ptr(); p.out = out.data_ptr()
     p.M = x2d.shape[0]; p.C = Cc; p.hidden = pack[1].numel() // 2; p.ldx = x2d.stride(0); p.ldo = out.stride(0); p.eps = eps
     _l.check(lib.ccnet_ff_geglu_fused_bf16(C.byref(p), _stream()), "ff_geglu_fused")
+    return out
+
+
+def xattn_pack(wq: torch.Tensor, bq: Optional[torch.Tensor], wo: torch.Tensor, heads: int):
+    """CrossAttention weights in the staging order of ccnet_xattn_fused_bf16 (include/ccnet_hip.h), or None when the kernel does
+    not cover the shape.  wq [C, C] (to_q, no transpose), bq [C] or None, wo [C, C] (to_out[0]).  Returns (w_packed bf16
+    [20, 10240], bq fp32 [C] in the packed row order): the softmax scale and log2 e are folded into to_q before its rounding."""
+    Cc = wq.shape[0]
+    if _l.load().ccnet_xattn_packed_bytes(Cc, heads) == 0 or wq.shape[1] != Cc or tuple(wo.shape) != (Cc, Cc):
+        return None
+    dev = wq.device
+    hd = Cc // heads
+    qs = math.log2(math.e) / math.sqrt(hd)
+    # accumulator register order -> natural head-dim order: position p of a 16-row group holds row pi[p] of that group
+    pi = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=dev)
+    rows = (torch.arange(Cc, device=dev) // 16) * 16 + pi[torch.arange(Cc, device=dev) % 16]
+    wqp = (wq.detach().float() * qs)[rows].to(BF16).reshape(Cc // 32, 32, Cc // 8, 8)      # [block][row][16-byte unit][8]
+    r = torch.arange(32, device=dev)
+    pos = torch.arange(Cc // 8, device=dev)
+    src = pos[None, :] ^ ((r[:, None] >> 1) & 7)                                           # position p of row r holds unit p ^ swz(r)
+    img_q = wqp[:, r[:, None], src]                                                        # [10, 32, units, 8]
+    t = torch.arange(8, device=dev)
+    hmap = torch.stack([torch.where(t < 4, 4 * hh + t, 4 + 4 * hh + t) for hh in (0, 1)])  # [2, 8]
+    wob = wo.detach().to(BF16).reshape(Cc, Cc // 16, 16)                                   # [cout][k-step][dim in k-step]
+    img_o = wob[:, :, hmap].permute(1, 2, 0, 3)                                            # [k-step (head-major), 2, cout, 8]
+    wp = torch.cat([img_q.reshape(-1), img_o.reshape(-1)]).reshape(-1, 10240).contiguous()
+    bqp = (bq.detach().float() * qs)[rows].contiguous() if bq is not None else torch.zeros(Cc, dtype=torch.float32, device=dev)
+    return wp, bqp
+
+
+def xattn_kv_image(kv: torch.Tensor, images: int, S: int, Cc: int) -> Optional[torch.Tensor]:
+    """The prompt's keys / values ([images * S, 2 C]: K | V, as to_k | to_v write them) as the per-image LDS images of
+    ccnet_xattn_fused_bf16: [80 keys][C] with swizzled 16-byte units, then V^T as [5 k-steps][2][C][8] with the keys of a k-step
+    in the order in which a lane holds the probabilities.  Once per prompt batch.  None: S > 80."""
+    if S > 80:
+        return None
+    dev = kv.device
+    k = torch.zeros((images, 80, Cc), dtype=BF16, device=dev)
+    v = torch.zeros((images, 80, Cc), dtype=BF16, device=dev)
+    k[:, :S] = kv[:, :Cc].reshape(images, S, Cc)
+    v[:, :S] = kv[:, Cc:2 * Cc].reshape(images, S, Cc)
+    r = torch.arange(80, device=dev)
+    pos = torch.arange(Cc // 8, device=dev)
+    src = pos[None, :] ^ ((r[:, None] >> 1) & 7)
+    kimg = k.reshape(images, 80, Cc // 8, 8)[:, r[:, None], src]                           # [images, 80, units, 8]
+    t = torch.arange(8, device=dev)
+    hmap = torch.stack([torch.where(t < 4, 4 * hh + t, 4 + 4 * hh + t) for hh in (0, 1)])  # [2, 8]
+    keys = 16 * torch.arange(5, device=dev)[:, None, None] + hmap[None]                    # [5, 2, 8]
+    vimg = v[:, keys].permute(0, 1, 2, 4, 3)                                               # [images, 5, 2, C, 8]
+    return torch.cat([kimg.reshape(images, -1), vimg.reshape(images, -1)], dim=1).contiguous()
+
+
+class XattnParams(C.Structure):
+    """Mirror of `ccnet_xattn_params` (include/ccnet_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("w_packed", C.c_void_p), ("bq", C.c_void_p), ("bo", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("kv_image", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("C", C.c_int32),
+                ("heads", C.c_int32), ("keys", C.c_int32), ("rows_per_image", C.c_int32), ("images", C.c_int32),
+                ("ldx", C.c_int32), ("ldo", C.c_int32), ("eps", C.c_float)]
+
+
+def xattn_fused(x2d: torch.Tensor, Cc: int, heads: int, pack, bo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                kv_image: torch.Tensor, S: int, rows_per_image: int, eps: float = 1e-5,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x + to_out(attention(to_q(LayerNorm(x)), K, V)) in one kernel; `pack` from xattn_pack, `kv_image` from xattn_kv_image (the
+    images that rows 0, rows_per_image, ... of x attend to).  Raises CcnetUnsupported for shapes the kernel does not cover."""
+    lib = _l.load()
+    _need_cuda(x2d, pack[0], kv_image)
+    if out is None:
+        out = torch.empty((x2d.shape[0], Cc), dtype=BF16, device=x2d.device)
+    p = XattnParams()
+    p.x = x2d.data_ptr(); p.w_packed = pack[0].data_ptr(); p.bq = pack[1].data_ptr(); p.bo = bo.data_ptr()
+    p.gamma = gamma.data_ptr(); p.beta = beta.data_ptr(); p.kv_image = kv_image.data_ptr(); p.out = out.data_ptr()
+    p.M = x2d.shape[0]; p.C = Cc; p.heads = heads; p.keys = S; p.rows_per_image = rows_per_image; p.images = kv_image.shape[0]
+    p.ldx = x2d.stride(0); p.ldo = out.stride(0); p.eps = eps
+    _l.check(lib.ccnet_xattn_fused_bf16(C.byref(p), _stream()), "xattn_fused")
     return out
 
 

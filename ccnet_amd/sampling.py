@@ -197,6 +197,8 @@ class Sampler:
         for k in ("kv_c", "kv_u"):
             for d, s_ in zip(dst[k][0], src[k][0]):
                 d.copy_(s_)
+                if getattr(d, "_ximg", None) is not None:  # (the same keys / values laid out for the fused cross-attention kernel)
+                    d._ximg.copy_(s_._ximg)
         dst["cond_emb"].t.copy_(src["cond_emb"].t)
         if src["cls"] is not None:
             dst["cls"].copy_(src["cls"])

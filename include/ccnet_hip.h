@@ -155,6 +155,38 @@ typedef struct ccnet_ff_params {
 int ccnet_ff_geglu_fused_bf16(const ccnet_ff_params* p /*host*/, void* stream);
 int64_t ccnet_ff_packed_bytes(int C, int hidden);
 
+/* Fused cross-attention branch of a transformer block: out = x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(d)) V) in one launch
+ * (monai-generative BasicTransformerBlock.forward: `x = self.attn2(self.norm2(x), context=context) + x`, CrossAttention with
+ * to_q / to_k / to_v / to_out; reached from util.py:944,1062).  K and V are the prompt's projections, which do not depend on the
+ * timestep: the caller computes them once per prompt batch (to_k | to_v as one linear layer) and lays them out per image as
+ *   [80 keys][C] bf16, keys >= `keys` zero, the 16-byte unit at position p of row r being unit p ^ ((r >> 1) & 7) of the key's K row,
+ *   [5][2][C][8] bf16: entry (s, hh, c, t) = V[16 s + (t < 4 ? 4 hh + t : 4 + 4 hh + t)][c]
+ * (ccnet_xattn_kv_image_bytes per image; ccnet_amd.ops.xattn_kv_image); rows [i * rows_per_image, (i + 1) * rows_per_image) of x
+ * attend to image i.  Served for C = 320, 5 heads of 64 and <= 80 keys (the 64x64 level of the SD-2.1 geometry; other shapes:
+ * CCNET_EUNSUP, run the layers one by one).
+ * w_packed (ccnet_amd.ops.xattn_pack): 20 stages of 20480 bytes.  Stages 0 .. 9: rows 32 i .. 32 i + 31 of to_q.weight * log2(e) /
+ * sqrt(64), rounded to bf16, with the rows of every 16-row group in the order (0..3, 8..11, 4..7, 12..15) and the 16-byte units of
+ * row r swizzled as above.  Stages 10 + 2 h + j (head h, j = 0, 1): k-steps s = 2 j, 2 j + 1 of the head's to_out columns as
+ * [2][C][8] each: entry (hh, n, t) = to_out.weight[n][64 h + 16 s + (t < 4 ? 4 hh + t : 4 + 4 hh + t)].  bq: to_q bias (if the
+ * layer has one) scaled and reordered like the rows; bo: to_out.bias. */
+typedef struct ccnet_xattn_params {
+    const void* x;         /* bf16 [M][ldx]: the branch's input rows (also the residual)           */
+    const void* w_packed;  /* bf16, see above                                                      */
+    const float* bq;       /* [C] or NULL                                                          */
+    const float* bo;       /* [C] or NULL                                                          */
+    const float* gamma;    /* LayerNorm weight [C]                                                 */
+    const float* beta;     /* LayerNorm bias [C]                                                   */
+    const void* kv_image;  /* bf16 [images][ccnet_xattn_kv_image_bytes / 2]                        */
+    void* out;             /* bf16 [M][ldo]                                                        */
+    int32_t M, C, heads, keys;          /* rows, channels, heads, keys per image (<= 80)          */
+    int32_t rows_per_image, images;     /* tokens per image (a multiple of 128), images in kv_image */
+    int32_t ldx, ldo;      /* row strides in elements (multiples of 8)                             */
+    float eps;             /* LayerNorm epsilon                                                    */
+} ccnet_xattn_params;
+int ccnet_xattn_fused_bf16(const ccnet_xattn_params* p /*host*/, void* stream);
+int64_t ccnet_xattn_packed_bytes(int C, int heads);
+int64_t ccnet_xattn_kv_image_bytes(int C, int heads);
+
 /* Direct 3x3 convolution for tiny channel counts at the network edges.
  *   conv_in_small : x fp32 NCHW [Nsrc][Cin<=8][H][W] (image n reads x[n % Nsrc]) -> NHWC bf16 [N][Hout][Wout][ldo]
  *                   out = act(conv(x) + bias) + res[n % Nres]   (res NHWC bf16, optional)

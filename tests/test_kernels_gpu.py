@@ -948,6 +948,62 @@ def test_ff_fused_320(cuda, case):
     assert (d > 0).float().mean().item() < 0.25
 
 
+@pytest.mark.parametrize("case", [(128, 128, 77), (4096 * 2, 4096, 77), (4096 + 200, 4096, 80), (128 * 600 - 37, 128, 17),
+                                  (32 * 4096, 4096, 77)])
+def test_xattn_fused_320(cuda, case):
+    """x + to_out(softmax(to_q(LayerNorm(x)) K^T / sqrt(64)) V) in one kernel (ccnet_xattn_fused_bf16; SURVEY Appendix A.3: norm2 +
+    CrossAttention + residual) at the G1 64x64-level width, 5 heads of 64: against the fp32 chain on the same bf16-rounded
+    operands, and against the three launches it replaces (LayerNorm + to_q with the scale folded in, flash kernel, to_out +
+    residual).  Cases: one tile; two images; ragged rows with 80 keys (no masked key); one image per tile, so that a workgroup
+    reloads K / V between its tiles, with few keys; the full CFG batch (several tiles per workgroup inside one image)."""
+    ops = _ops()
+    M, HW, S = case
+    images = -(-M // HW)
+    g = torch.Generator().manual_seed(1234 + M)
+    xs = torch.randn(M, 320, generator=g)
+    xs[1::7] += 10.0
+    x = xs.to(torch.bfloat16).to(cuda)
+    gamma, beta = (1 + 0.2 * torch.randn(320, generator=g)).to(cuda), (0.3 * torch.randn(320, generator=g)).to(cuda)
+    wq = (torch.randn(320, 320, generator=g) * (2.0 / math.sqrt(320))).to(cuda)
+    wo = (torch.randn(320, 320, generator=g) / math.sqrt(320)).to(cuda)
+    bo = (0.5 * torch.randn(320, generator=g)).to(cuda)
+    kv = torch.randn(images * S, 640, generator=g).to(torch.bfloat16).to(cuda)
+    pack = ops.xattn_pack(wq, None, wo, 5)
+    assert pack is not None and pack[0].shape == (20, 10240)
+    img = ops.xattn_kv_image(kv, images, S, 320)
+    assert img.shape == (images, 51200)
+    out = ops.xattn_fused(x, 320, 5, pack, bo, gamma, beta, img, S, HW, 1e-5)
+    # fp32 reference on the same rounded operands (the kernel rounds to_q's weight after folding the scale in)
+    qs = math.log2(math.e) / 8.0
+    wqb = (wq * qs).to(torch.bfloat16).float() / qs
+    ln = F.layer_norm(x.float(), (320,), gamma, beta, 1e-5).to(torch.bfloat16).float()
+    q = (ln @ wqb.T).to(torch.bfloat16).float()
+    ref = torch.empty(M, 320, device=cuda)
+    for i in range(images):
+        r0, r1 = i * HW, min((i + 1) * HW, M)
+        k = kv[i * S:(i + 1) * S, :320].float().reshape(S, 5, 64).permute(1, 0, 2)
+        v = kv[i * S:(i + 1) * S, 320:].float().reshape(S, 5, 64).permute(1, 0, 2)
+        qi = q[r0:r1].reshape(-1, 5, 64).permute(1, 0, 2)
+        p_ = torch.softmax(qi @ k.transpose(1, 2) / 8.0, dim=-1)
+        ref[r0:r1] = (p_ @ v).permute(1, 0, 2).reshape(-1, 320)
+    ref = ref.to(torch.bfloat16).float() @ wo.to(torch.bfloat16).float().T + bo + x.float()
+    _close(out.float(), ref, atol=4e-2, what=f"fused cross-attention {case}")
+    if M % HW == 0:
+        t = ops.layernorm(x, 320, gamma, beta)
+        q3 = ops.linear(t, (wq * qs).to(torch.bfloat16).contiguous(), None, 320, 320)
+        o3 = ops.attention_d64(q3, kv[:, :320], kv[:, 320:], images, 5, HW, S, 1.0 / 8.0, prescaled=True)
+        un = ops.linear(o3, wo.to(torch.bfloat16).contiguous(), bo, 320, 320, res1=x)
+        d = (out.float() - un.float()).abs()
+        scale = un.float().abs().max().item()
+        assert d.max().item() <= 2.0 ** -5 * scale, f"vs the three-launch path: max {d.max().item()} (|out| max {scale})"
+
+
+def test_xattn_fused_unsupported_shape(cuda):
+    ops = _ops()
+    assert ops.xattn_pack(torch.zeros(640, 640), None, torch.zeros(640, 640), 10) is None
+    assert ops.xattn_kv_image(torch.zeros(2 * 96, 640, dtype=torch.bfloat16), 2, 96, 320) is None
+
+
 def test_ff_fused_unsupported_shape(cuda):
     ops = _ops()
     assert ops.ff_pack(torch.zeros(2 * 2560, 640), torch.zeros(2 * 2560), torch.zeros(640, 2560)) is None

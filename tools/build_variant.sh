@@ -8,7 +8,7 @@ mkdir -p ../../build_var
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value $flags -Rpass-analysis=kernel-resource-usage -c $src.hip -o ../../build_var/${src}_$name.o 2> ../../build_var/${src}_$name.res
 grep -E "ScratchSize \[bytes/lane\]: [1-9]" ../../build_var/${src}_$name.res && echo "SPILL in variant $name" || true
 objs=""
-for s in gemm_conv norm attention elementwise train fused_ff; do
+for s in gemm_conv norm attention elementwise train fused_ff fused_xattn; do
   if [ $s = $src ]; then objs="$objs ../../build_var/${src}_$name.o"; else objs="$objs $s.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_var/lib_$name.so $objs
