@@ -265,11 +265,17 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
             // 2 i + p of the row (re-read: L2 / Infinity Cache), one 16-byte store each.
             if (ti > 0) {
                 __bf16* orow = a.out + (long long)prow * a.ldo + 8 * hh;
+                u32x4 rr[FF_C / 32][2];  // (requested in two bursts of five blocks: two L2 round trips instead of ten)
 #pragma unroll
                 for (int i = 0; i < FF_C / 32; ++i) {
-                    u32x4 rr[2];
+                    if (i % 5 == 0) {
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) rr[p] = (FF_DIAG & 16) ? u32x4{0u, 0u, 0u, 0u} : *(const u32x4*)(pxp + 32 * i + 16 * p);
+                        for (int i2 = i; i2 < i + 5; ++i2)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+                                rr[i2][p] = (FF_DIAG & 16) ? u32x4{0u, 0u, 0u, 0u} : *(const u32x4*)(pxp + 32 * i2 + 16 * p);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         float w8[8], r8[8];
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const FfArgs a) {
                             swap32(lo, hi);
                             w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
                         }
-                        unpack8(rr[p], r8);
+                        unpack8(rr[i][p], r8);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) w8[e] += r8[e];
                         if (prok) *(u32x4*)(orow + 32 * i + 16 * p) = pack8(w8);
