@@ -1652,13 +1652,14 @@ int plan_conv(int M, int Cout, int KT, int batch, bool geglu, bool can_split, in
             const long long t128 = tiles(128, 320);
             if (res_only && KT <= 5 && t128 >= 512) return 30;
             // (K up to 5120: ff.linear2 of the 16x16 level 995 vs 936 TFLOP/s, with residual 964 vs 915; at K = 11520 the big tile wins 1144 vs 962)
-            // (round 3, 16x16x32 instances, tools/sweep_plan.sh: at K = 5120 two K-slices of the big tile now win, 982 / 947 (+ res)
-            // against 924 / 900 TFLOP/s)
-            if (t128 > 128 && t128 <= 256 && tiles(256, 320) < 200 && KT == 80 && can_split) { *S_out = 2; return 23; }
+            // (round 3, 16x16x32 instances, tools/sweep_plan.sh: at K = 5120 two K-slices of the big tile are 6-8 % faster, 982 / 947
+            // (+ res) against 924 / 900 TFLOP/s, but write 84 MB of fp32 partials per launch where the output is 21 MB: not taken,
+            // 0.25 % of the pipeline against 3 % more bytes across the L2 boundary over all launches)
             if (t128 > 128 && t128 <= 256 && tiles(256, 320) < 200 && KT <= 80 && KT >= 10) return 29;
         }
         // qkv of the 16x16 level (8192 x 3840 x 1280): 480 tiles of 256 x 256 fill two rounds better than 384 of 256 x 320 fill
-        // one and a half: 1043-1052 against 918-924 TFLOP/s (same sweep)
+        // one and a half: 1043-1052 against 918-924 TFLOP/s (same sweep; the bytes across the L2 boundary are the same either
+        // way, ~250-300 MB per launch: the 9.8 MB of weights thrash a 4 MB L2 once per pixel panel under both tilings)
         if ((Cout % 256) == 0 && (Cout % 320) == 0 && batch == 1 && KT > 10 && KT <= 20 && tiles(256, 256) >= 400 &&
             tiles(256, 256) <= 512 && tiles(256, 320) < 512) return 10;
         if ((Cout % 320) == 0 && tiles(256, 320) >= 200) return 23;
