@@ -257,6 +257,48 @@ def test_cabi_exports_every_declared_symbol():
     assert l.ccnet_strerror(-1).decode().startswith("invalid")
     import ctypes
     assert ctypes.sizeof(lib.ConvParams) == 9 * 8 + 23 * 4 + 4 + 3 * 8 + 16 + 16 + 8 + 8  # struct layout of ccnet_conv_params
+    from ccnet_amd import ops
+    assert ctypes.sizeof(ops.FfParams) == 7 * 8 + 5 * 4 + 4           # ccnet_ff_params: 7 pointers, 5 int32, float
+    assert ctypes.sizeof(ops.XattnParams) == 8 * 8 + 8 * 4 + 4 + 4    # ccnet_xattn_params: 8 pointers, 8 int32, float (+ tail padding)
+    assert l.ccnet_ff_packed_bytes(320, 1280) == 80 * 30720 and l.ccnet_ff_packed_bytes(640, 2560) == 0
+    assert l.ccnet_xattn_packed_bytes(320, 5) == 20 * 20480 and l.ccnet_xattn_kv_image_bytes(320, 5) == 102400
+    assert l.ccnet_xattn_packed_bytes(640, 10) == 0
+
+
+def test_xattn_pack_and_kv_image_layouts():
+    """Host-side layouts of the fused cross-attention kernel (include/ccnet_hip.h: ccnet_xattn_params) against their definitions,
+    element by element on a few probes."""
+    import math
+    from ccnet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    wq, wo = torch.randn(320, 320, generator=g), torch.randn(320, 320, generator=g)
+    bq = torch.randn(320, generator=g)
+    wp, bqp = ops.xattn_pack(wq, bq, wo, 5)
+    qs = math.log2(math.e) / 8.0
+    pi = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+    flat = wp.reshape(-1)
+    wqs = (wq * qs).to(torch.bfloat16)
+    for blk, r, unit, e in [(0, 0, 0, 0), (3, 17, 11, 5), (9, 31, 39, 7), (4, 6, 8, 2)]:
+        row = 32 * blk + r
+        src_row = (row // 16) * 16 + pi[row % 16]
+        src_unit = unit ^ ((r >> 1) & 7)                       # position `unit` of row r holds unit `unit ^ swz(r)`
+        assert flat[blk * 10240 + r * 320 + unit * 8 + e] == wqs[src_row, src_unit * 8 + e]
+        assert bqp[row] == (bq * qs)[src_row]
+    wob = wo.to(torch.bfloat16)
+    for h, s_, hh, n, t in [(0, 0, 0, 0, 0), (2, 3, 1, 200, 6), (4, 1, 0, 319, 3)]:
+        dim = 64 * h + 16 * s_ + (4 * hh + t if t < 4 else 4 + 4 * hh + t)
+        assert flat[10 * 10240 + ((h * 4 + s_) * 2 + hh) * 2560 + n * 8 + t] == wob[n, dim]
+    kv = torch.randn(2 * 77, 640, generator=g).to(torch.bfloat16)
+    img = ops.xattn_kv_image(kv, 2, 77, 320)
+    assert img.shape == (2, 51200)
+    for i, key, unit, e in [(0, 0, 0, 0), (1, 76, 39, 7), (1, 33, 12, 4)]:
+        assert img[i, key * 320 + unit * 8 + e] == kv[i * 77 + key, (unit ^ ((key >> 1) & 7)) * 8 + e]
+    assert (img[:, 77 * 320:80 * 320] == 0).all()              # padded keys
+    for i, s_, hh, c, t in [(0, 0, 0, 0, 0), (1, 4, 1, 300, 2), (1, 2, 0, 17, 7)]:
+        key = 16 * s_ + (4 * hh + t if t < 4 else 4 + 4 * hh + t)
+        exp = kv[i * 77 + key, 320 + c] if key < 77 else 0
+        assert img[i, 25600 + ((s_ * 2 + hh) * 320 + c) * 8 + t] == exp
+    assert ops.xattn_kv_image(torch.zeros(2 * 96, 640, dtype=torch.bfloat16), 2, 96, 320) is None
 
 
 # ------------------------------------------------------------------ sharding (world_size 2, gloo)
