@@ -460,6 +460,50 @@ class _Trunk(nn.Module):
             skip = ops.conv(x, p["skip"][0], p["skip"][1], cout, R=1, pad=0, x2=x2)
         return ops.conv(h, p["c2"][0], p["c2"][1], cout, R=3, res1=skip, res2=res2)
 
+    @staticmethod
+    def _cross_attn(p, t, x: Act, kv, S, B, T, heads, hc, inner, scale, pre, inl, dup_to, attend):
+        """t + attn2(norm2(t), context) of a transformer block (rows t, the block's input x).  Returns (t, halves, x, B): with shared
+        CFG halves (dup_to) the result has dup_to images while `halves` keeps the B-image block input for proj_out's residual."""
+        ximg = getattr(kv, "_ximg", None) if p["xap"] is not None else None
+        if ximg is not None and T % 128 == 0 and t.shape[0] >= FF_FUSED_MIN_ROWS and (dup_to is None or hc == 64):
+            # norm2 -> to_q -> cross-attention -> to_out -> + t in one launch; with shared CFG halves once per half (the same B
+            # query / residual rows, that half's keys and values) into the halves of one tensor
+            try:
+                if dup_to is None:
+                    return ops.xattn_fused(t, inner, heads, p["xap"], p["o2"][1], p["ln2"][0], p["ln2"][1], ximg, S, T), None, x, B
+                t2 = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
+                for hf in (0, 1):
+                    ops.xattn_fused(t, inner, heads, p["xap"], p["o2"][1], p["ln2"][0], p["ln2"][1], ximg[hf * B:(hf + 1) * B], S, T,
+                                    out=t2[hf * B * T:(hf + 1) * B * T])
+                return t2, x, x, B
+            except CcnetUnsupported:  # (decided from the shapes before anything is launched)
+                pass
+        q = None
+        if inl:
+            w, b, cs = p["q2i"]
+            try:
+                q = ops.linear(t, w, b, inner, inner, colsum=cs)
+            except CcnetUnsupported:
+                pass
+        if q is None:
+            q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
+        if dup_to is not None and hc == 64:
+            # From here on the two halves differ (their prompts do).  Nothing is copied: the cross-attention and its output
+            # projection run once per half -- the same B query / residual rows, that half's keys and values -- into the
+            # two halves of one tensor, and so does proj_out in the caller.
+            o = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
+            t2 = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
+            rows = lambda tt, hf, n: Act(tt[hf * B * n:(hf + 1) * B * n], 1, B * n, 1, tt.shape[1])
+            for hf in (0, 1):
+                kvh = kv[hf * B * S:(hf + 1) * B * S]
+                ops.attention_d64(q, kvh[:, :inner], kvh[:, inner:], B, heads, T, S, scale, prescaled=pre, out=o[hf * B * T:(hf + 1) * B * T])
+                ops.conv(rows(o, hf, T), p["o2"][0], p["o2"][1], inner, R=1, pad=0, res1=Act(t, 1, B * T, 1, inner), out=rows(t2, hf, T))
+            return t2, x, x, B
+        if dup_to is not None:
+            q, t, x, B = torch.cat([q, q]), torch.cat([t, t]), _dup_act(x), dup_to
+        o = attend(q, kv[:, :inner], kv[:, inner:], S, B)
+        return ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t), None, x, B
+
     def _run_attn(self, pk, a, x: Act, kv: torch.Tensor, S: int, res2: Optional[Act] = None, dup_to: Optional[int] = None):
         """dup_to: x holds the first x.N images of a batch of dup_to = 2 x.N whose halves are identical so far (CFG_SHARE): the
         block runs on x.N images up to attn2's query and on dup_to images from the cross-attention on (kv, res2 and the result
@@ -476,10 +520,11 @@ class _Trunk(nn.Module):
         pre = (not LN_FOLD) and p["qkv1s"] is not None
         halves = None
 
-        def attend(q, k, v, Skv):
+        def attend(q, k, v, Skv, Bq=None):
+            Bq = B if Bq is None else Bq
             if hc == 64:  # flash kernel (SD-2.1 geometry)
-                return ops.attention_d64(q, k, v, B, heads, T, Skv, scale, prescaled=pre)
-            return ops.attention_generic(q, k, v, B, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
+                return ops.attention_d64(q, k, v, Bq, heads, T, Skv, scale, prescaled=pre)
+            return ops.attention_generic(q, k, v, Bq, heads, T, Skv, hc, scale)  # e.g. one head of 512 / 768 (repo YAML)
         h = ops.groupnorm(x, p["norm"][0], p["norm"][1], self.norm_num_groups, self.transformer_norm_eps, False)
         if LN_FOLD:
             # The three LayerNorms never materialise.  Their row statistics come out of the epilogue of the layer that writes
@@ -514,53 +559,7 @@ class _Trunk(nn.Module):
                 qkv = ops.linear(ops.layernorm(t, inner, *p["ln1"]), p["qkv1s"] if pre else p["qkv1"], None, 3 * inner, inner)
             o = attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], T)
             t = ops.linear(o, p["o1"][0], p["o1"][1], inner, inner, res1=t)
-            ximg = getattr(kv, "_ximg", None) if p["xap"] is not None else None
-            xa = ximg is not None and T % 128 == 0 and t.shape[0] >= FF_FUSED_MIN_ROWS and (dup_to is None or hc == 64)
-            q = None
-            if xa:
-                # norm2 -> to_q -> cross-attention -> to_out -> + t in one launch; with shared CFG halves once per half (the same B
-                # query / residual rows, that half's keys and values) into the halves of one tensor
-                try:
-                    if dup_to is not None:
-                        t2 = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
-                        for hf in (0, 1):
-                            ops.xattn_fused(t, inner, heads, p["xap"], p["o2"][1], p["ln2"][0], p["ln2"][1], ximg[hf * B:(hf + 1) * B],
-                                            S, T, out=t2[hf * B * T:(hf + 1) * B * T])
-                        t, halves = t2, x
-                    else:
-                        t = ops.xattn_fused(t, inner, heads, p["xap"], p["o2"][1], p["ln2"][0], p["ln2"][1], ximg, S, T)
-                except CcnetUnsupported:
-                    xa = False
-            if not xa and inl:
-                w, b, cs = p["q2i"]
-                try:
-                    q = ops.linear(t, w, b, inner, inner, colsum=cs)
-                except CcnetUnsupported:
-                    pass
-            if xa:
-                pass
-            elif q is None:
-                q = ops.linear(ops.layernorm(t, inner, *p["ln2"]), p["q2s"] if pre else p["q2"], None, inner, inner)
-            if xa:
-                pass
-            elif dup_to is not None and hc == 64:
-                # From here on the two halves differ (their prompts do).  Nothing is copied: the cross-attention and its output
-                # projection run once per half -- the same B query / residual rows, that half's keys and values -- into the
-                # two halves of one tensor, and so does proj_out below.
-                o = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
-                t2 = torch.empty((2 * B * T, inner), dtype=t.dtype, device=t.device)
-                rows = lambda tt, hf, n: Act(tt[hf * B * n:(hf + 1) * B * n], 1, B * n, 1, tt.shape[1])
-                for hf in (0, 1):
-                    kvh = kv[hf * B * S:(hf + 1) * B * S]
-                    ops.attention_d64(q, kvh[:, :inner], kvh[:, inner:], B, heads, T, S, scale, prescaled=pre, out=o[hf * B * T:(hf + 1) * B * T])
-                    ops.conv(rows(o, hf, T), p["o2"][0], p["o2"][1], inner, R=1, pad=0, res1=Act(t, 1, B * T, 1, inner), out=rows(t2, hf, T))
-                t, halves = t2, x
-            else:
-                halves = None
-                if dup_to is not None:
-                    q, t, x, B = torch.cat([q, q]), torch.cat([t, t]), _dup_act(x), dup_to
-                o = attend(q, kv[:, :inner], kv[:, inner:], S)
-                t = ops.linear(o, p["o2"][0], p["o2"][1], inner, inner, res1=t)
+            t, halves, x, B = self._cross_attn(p, t, x, kv, S, B, T, heads, hc, inner, scale, pre, inl, dup_to, attend)
             if p["ffp"] is not None and t.shape[0] >= FF_FUSED_MIN_ROWS:
                 gl = None
                 t = ops.ff_fused(t, inner, p["ffp"], p["ff2"][1], p["ln3"][0], p["ln3"][1])
