@@ -15,7 +15,7 @@
 //      P rounded to bf16 in register order is the B operand of O^T = V^T P (5 k-steps of 16 keys x 2 dim blocks; V^T sits in LDS
 //      with its keys permuted to that order), O / rowsum rounded to bf16 is the B operand of to_out for the head's 64 columns
 //      (40 MFMAs; Wo's columns permuted to the order in which a lane holds them), accumulated over the heads in 160 registers;
-//   4. + bias + the raw rows (re-read: L2 / Infinity Cache) -> store.
+//   4. -> store (bias and the raw rows, the residual, are what the accumulators start from: the rows are read from HBM once).
 // The weights stream through LDS by LDS-DMA in 20 stages of 20 KB per tile (10 Wq blocks, then per head two halves of its Wo
 // columns), packed on the host in exactly that order (ccnet_amd.ops.xattn_pack); the image's K / V^T (100 KB, built once per
 // prompt batch by ccnet_amd.ops.xattn_kv_image) stay resident while the workgroup walks consecutive tiles of that image.
@@ -93,9 +93,25 @@ __global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
         lo = r[0]; hi = r[1];
     };
 
+    // selection matrices for the residual (see the accumulator start below): A operand rows are couts of a 32-block, k the 16
+    // channels of one 16-byte-unit pair; lane (l31, hh) holds A[l31][8 hh + t]: sel0 = ones at cout == k, sel1 at cout == 16 + k
+    bf16x8 sel0, sel1;
+    {
+        u32x4 z0 = {0u, 0u, 0u, 0u}, z1 = {0u, 0u, 0u, 0u};
+        const int t0 = l31 - 8 * hh, t1 = l31 - 16 - 8 * hh;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned one = 0x3F80u << (16 * (t & 1));
+            if (t == t0) z0[t >> 1] |= one;
+            if (t == t1) z1[t >> 1] |= one;
+        }
+        sel0 = __builtin_bit_cast(bf16x8, z0);
+        sel1 = __builtin_bit_cast(bf16x8, z1);
+    }
     int gs = 0, cur_img = -1;
-    // a tile's raw rows are requested one tile ahead (during the previous tile's heads, when the registers of its normalised
-    // rows are free): their HBM latency hides behind that tile's MFMAs
+    // a tile's raw rows: read once, they feed the LayerNorm and (through the accumulator start) the residual.  (Requesting them one
+    // tile ahead, during the previous tile's heads, hid their latency -- 3 % -- but needs 80 registers that the accumulators, now
+    // live from the tile's start, do not leave.)
     u32x4 xr[XA_KS];
     auto request_rows = [&](int tile) {
         const int r = tile * 128 + wave * 32 + l31;
@@ -103,8 +119,8 @@ __global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
 #pragma unroll
         for (int ks = 0; ks < XA_KS; ++ks) xr[ks] = *(const u32x4*)(p + 16 * ks);
     };
-    request_rows(t_lo);
     for (int tile = t_lo; tile < t_hi; ++tile) {
+        request_rows(tile);
         const int row = tile * 128 + wave * 32 + l31;
         const bool rok = row < a.M;
         const __bf16* xp = a.x + (long long)(rok ? row : a.M - 1) * a.ldx + 8 * hh;
@@ -125,6 +141,9 @@ __global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
         }
         // ---- the wave's 32 rows -> LayerNorm -> bf16 (two-pass statistics over the lane's 160 values + its lane ^ 32 partner's)
         bf16x8 xh[XA_KS];
+        // the outputs of the wave's rows accumulate over the heads; they START at to_out's bias + the raw rows (the residual), taken
+        // below while the rows are in registers
+        f32x16 acc_o[XA_C / 32];
         {
             float s = 0.f;
 #pragma unroll
@@ -162,6 +181,22 @@ __global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
                     o[4 + e] = (f[4 + e] - mean) * rstd * g1[e] + t1[e];
                 }
                 xh[ks] = (XA_DIAG & 8) ? __builtin_bit_cast(bf16x8, xr[ks]) : __builtin_bit_cast(bf16x8, pack8(o));
+            }
+            // acc_o[i] = bias + rows: the raw rows are already B operands (k = 16 channels of a unit pair), so two MFMAs per 32
+            // outputs against selection matrices (ones where cout == channel; exact: 1.0 x bf16, fp32 sums) put them into the
+            // accumulator layout on the matrix core -- no vector instructions, no extra registers, no second read of the rows
+#pragma unroll
+            for (int i = 0; i < XA_C / 32; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = *(const f32x4*)(bos + 32 * i + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc_o[i][4 * q + e] = t[e];
+                }
+                if (!(XA_DIAG & 8)) {
+                    acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, __builtin_bit_cast(bf16x8, xr[2 * i]), acc_o[i], 0, 0, 0);
+                    acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, __builtin_bit_cast(bf16x8, xr[2 * i + 1]), acc_o[i], 0, 0, 0);
+                }
             }
         }
         // stage gs: wait until it has landed (this wave's pieces: vmcnt; the others': barrier; every wave has then also left stage
@@ -212,17 +247,7 @@ __global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
             qf[2 * i + 1] = __builtin_bit_cast(bf16x8, pack8(hi8));
         }
 
-        // ---- the heads; the outputs of the wave's rows accumulate over them (start: to_out's bias)
-        f32x16 acc_o[XA_C / 32];
-#pragma unroll
-        for (int i = 0; i < XA_C / 32; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = *(const f32x4*)(bos + 32 * i + 8 * q + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc_o[i][4 * q + e] = t[e];
-            }
-        if (tile + 1 < t_hi) request_rows(tile + 1);
+        // ---- the heads
 #pragma unroll
         for (int h = 0; h < XA_HEADS; ++h) {
             // scores^T: key 32 kb + 8 q + 4 hh + e of token l31 in register 4 q + e of block kb (rows 80 .. 95 of block 2 read
@@ -328,30 +353,21 @@ __global__ __launch_bounds__(256, 1) void xattn320_kernel(const XaArgs a) {
                 }
             }
         }
-        // ---- the tile's outputs leave.  After the permlane32 swap a lane owns couts 32 i + 16 p + 8 hh .. + 7 of its row; the
-        // residual is the raw 16-byte unit 2 i + p of the row (re-read), one 16-byte store each.
+        // ---- the tile's outputs leave.  After the permlane32 swap a lane owns couts 32 i + 16 p + 8 hh .. + 7 of its row: one
+        // 16-byte store each (the residual is in the accumulators since the tile's start).
         {
             __bf16* orow = a.out + (long long)row * a.ldo + 8 * hh;
-            u32x4 rr[XA_C / 32][2];  // (one burst: the scores' and probabilities' registers are free by now)
-#pragma unroll
-            for (int i = 0; i < XA_C / 32; ++i)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) rr[i][p] = (XA_DIAG & 8) ? u32x4{0u, 0u, 0u, 0u} : *(const u32x4*)(xp + 32 * i + 16 * p);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < XA_C / 32; ++i) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    float w8[8], r8[8];
+                    float w8[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         unsigned lo = __float_as_uint(acc_o[i][8 * p + e]), hi = __float_as_uint(acc_o[i][8 * p + 4 + e]);
                         swap32(lo, hi);
                         w8[e] = __uint_as_float(lo); w8[4 + e] = __uint_as_float(hi);
                     }
-                    unpack8(rr[i][p], r8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) w8[e] += r8[e];
                     if (rok) *(u32x4*)(orow + 32 * i + 16 * p) = pack8(w8);
                 }
             }
