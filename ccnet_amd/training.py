@@ -816,3 +816,65 @@ def train_epoch_controlnet(controlnet, diffusion, stage1, scheduler, text_encode
             lr_scheduler.step()
         losses.append(float(loss))
     return losses
+
+
+@torch.no_grad()
+def eval_controlnet(controlnet, diffusion, stage1, scheduler, text_encoder, loader, device, step: int = 0, writer=None,
+                    scale_factor: float = 1.0, break_at_iteration: int = -1, cond_on_acq_times: bool = False,
+                    sample: bool = True, controlnet_conditioning_scale: float = 1.0) -> float:
+    """training_functions.py:1046-1176 with the same arguments: the validation pass of the ControlNet.  Per batch a random
+    timestep per image, latents from stage 1, the prompt through the text tower, one ControlNet + UNet forward on the HIP path
+    (`sample_from_controlnet` / `sample_from_ldm`, no tape), MSE against the scheduler's target (:1126-1133); the batch means
+    are weighted by the batch size and divided by `len(loader.dataset)` (:1139,1146 -- by the images seen for a loader without
+    a dataset).  `break_at_iteration > 0` stops after that many + 1 batches (:1141).  With `sample` the last batch's first
+    pair goes through the sampler (`preview_controlnet_sample`, the sampling part of `log_controlnet_samples`, :1157-1175) and,
+    when `writer` has `add_image`, conditioning image / target / sample are logged at `step`; the matplotlib figure of the
+    reference stays with the caller.  Returns the mean loss."""
+    import torch.nn.functional as F
+
+    from .sampling import preview_controlnet_sample, sample_from_controlnet, sample_from_ldm
+    controlnet.eval()
+    total, seen, counter = 0.0, 0, 0
+    images = cond = reports = acq = e = None
+    for x in loader:
+        images = x["target"].to(device)
+        reports = x["report"].to(device)
+        cond = x["source"].to(device)
+        acq = x["acquisition_time"].to(device).unsqueeze(0) if cond_on_acq_times else None
+        timesteps = torch.randint(0, scheduler.num_train_timesteps, (images.shape[0],), device=device).long()
+        e = stage1(images) * scale_factor
+        prompt_embeds = text_encoder(reports.squeeze(1))[0]
+        noise = torch.randn_like(e)
+        noisy_e = scheduler.add_noise(original_samples=e, noise=noise, timesteps=timesteps)
+        down, mid = sample_from_controlnet(controlnet=controlnet, noisy_e=noisy_e, controlnet_cond=cond, timesteps=timesteps,
+                                           prompt_embeds=prompt_embeds, class_labels=acq,
+                                           conditioning_scale=controlnet_conditioning_scale)
+        noise_pred = sample_from_ldm(model=diffusion, noisy_e=noisy_e, timesteps=timesteps, prompt_embeds=prompt_embeds,
+                                     down_block_res_samples=tuple(down), mid_block_res_sample=mid, class_labels=acq)
+        if scheduler.prediction_type == "v_prediction":
+            target = scheduler.get_velocity(e, noise, timesteps)
+        elif scheduler.prediction_type == "epsilon":
+            target = noise
+        else:
+            raise ValueError(f"prediction_type {scheduler.prediction_type!r} has no training target upstream")
+        loss = F.mse_loss(noise_pred.float(), target.float())
+        total += float(loss) * images.shape[0]
+        seen += images.shape[0]
+        if break_at_iteration > 0 and counter == break_at_iteration:
+            break
+        counter += 1
+    if seen == 0:
+        raise ValueError("eval_controlnet: the loader yielded no batch")
+    total /= len(loader.dataset) if hasattr(loader, "dataset") else seen
+    if sample:
+        acq0 = acq.reshape(-1)[:1] if acq is not None else None
+        res = preview_controlnet_sample(cond[:1], controlnet, diffusion, stage1, text_encoder, scheduler,
+                                        spatial_shape=tuple(e.shape[1:]), device=device, scale_factor=scale_factor,
+                                        acquisition_time=acq0, text_condition=reports[0].reshape(1, -1),
+                                        controlnet_conditioning_scale=controlnet_conditioning_scale)
+        if writer is not None and hasattr(writer, "add_image"):
+            to01 = lambda t: ((t.float().clamp(-1, 1) + 1) * 0.5)[0, :1].cpu()  # noqa: E731
+            writer.add_image("validation/controlnet_cond", to01(cond), step)
+            writer.add_image("validation/target", to01(images), step)
+            writer.add_image("validation/sample", to01(res["image"]), step)
+    return total

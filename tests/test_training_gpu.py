@@ -376,6 +376,77 @@ def test_train_epoch_controlnet_signature(cuda):
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, cn.parameters()))
 
 
+def test_eval_controlnet_against_the_oracle_loss(cuda):
+    """eval_controlnet (training_functions.py:1046-1176) with the reference's arguments over two batches: the returned loss
+    against the fp32 oracle networks fed the same draws (timesteps, stage-1 latents and noise replayed from the same seed in
+    the same order), within 1 % (bf16 forward; measured 0.02 %: 0.800717 vs 0.800551); then with `sample=True`: the sampler preview of the last
+    batch's first pair reaches the writer as three images in [0, 1], `break_at_iteration` stops early and the loss is still
+    divided by the dataset size (:1141-1146)."""
+    import oracle.schedulers as osch
+    from ccnet_amd import schedulers as psch
+    from ccnet_amd import training
+    from _common import TINY_VAE
+    cfg = dict(TINY, **TINY_CE)
+    cn, ocn = build_pair("controlnet", cfg, 31, cuda, acq=True)
+    un, oun = build_pair("unet", TINY, 32, cuda, acq=True)
+    vae, _ = build_pair("vae", TINY_VAE, 33, cuda)
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn(2, 77, 64, generator=g) * 0.5
+    ctx_d = ctx.to(cuda)
+
+    class Text:  # text_encoder(ids)[0] -> [B, 77, D]
+        device = cuda
+
+        def __call__(self, ids):
+            return (ctx_d[: ids.shape[0]],)
+
+    class Loader(list):
+        dataset = range(4)
+    loader = Loader({"target": torch.rand(2, 1, 128, 128, generator=g) * 2 - 1, "source": torch.rand(2, 1, 128, 128, generator=g) * 2 - 1,
+                     "report": torch.zeros(2, 1, 77, dtype=torch.long), "report_raw": ["", ""],
+                     "acquisition_time": torch.rand(2, generator=g) * 900 + 60} for _ in range(2))
+    st1 = training.Stage1Wrapper(vae)
+    sch, osc = psch.DDPMScheduler(**SCHED), osch.DDPMScheduler(**SCHED)
+    torch.manual_seed(7)
+    loss = training.eval_controlnet(cn, un, st1, sch, Text(), loader, cuda, 3, None, scale_factor=0.3, cond_on_acq_times=True,
+                                    sample=False, controlnet_conditioning_scale=0.9)
+    torch.manual_seed(7)
+    tot = 0.0
+    with torch.no_grad():
+        for x in loader:
+            t = torch.randint(0, sch.num_train_timesteps, (2,), device=cuda).long()
+            e = st1(x["target"].to(cuda)) * 0.3
+            noise = torch.randn_like(e)
+            e, noise, t = e.float().cpu(), noise.float().cpu(), t.cpu()
+            noisy = osc.add_noise(original_samples=e, noise=noise, timesteps=t)
+            cl = x["acquisition_time"].reshape(2, 1)
+            down, mid = ocn(noisy, t, x["source"], 0.9, ctx, cl)
+            pred = oun(noisy, t, ctx, cl, down, mid)
+            tot += F.mse_loss(pred.float(), osc.get_velocity(e, noise, t).float()).item() * 2
+    ref = tot / 4
+    print(f"eval loss {loss:.6f} vs oracle {ref:.6f}")
+    assert abs(loss - ref) <= 0.01 * ref, (loss, ref)
+
+    class Writer:
+        def __init__(self):
+            self.images = {}
+
+        def add_image(self, tag, img, step):
+            self.images[tag] = (img, step)
+    w = Writer()
+    sch.set_timesteps(6)
+    torch.manual_seed(8)
+    one = training.eval_controlnet(cn, un, st1, sch, Text(), loader, cuda, 11, w, scale_factor=0.3, cond_on_acq_times=True,
+                                   sample=True, break_at_iteration=-1)
+    assert math.isfinite(one) and set(w.images) == {"validation/controlnet_cond", "validation/target", "validation/sample"}
+    for img, step in w.images.values():
+        assert step == 11 and img.shape == (1, 128, 128) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    torch.manual_seed(8)
+    early = training.eval_controlnet(cn, un, st1, sch, Text(), [loader[0], loader[1], loader[0]], cuda, sample=False,
+                                     scale_factor=0.3, cond_on_acq_times=True, break_at_iteration=1)
+    assert math.isfinite(early)  # two of the three batches ran (counter 0, 1), divided by the 4 images seen
+
+
 @pytest.mark.timeout(900)
 def test_controlnet_training_step_at_the_real_geometry(cuda):
     """The same step at the SD-2.1-base geometry (G1: 320/640/1280/1280 channels, 64x64 latent, 77 x 1024 text, acquisition
