@@ -36,6 +36,9 @@ from .ops import Act
 BF16 = torch.bfloat16
 
 
+_OPERAND_LIMIT = 0x7fffffff  # bytes one operand of ccnet_conv_gemm_bf16 may span (gemm_conv.hip: 32-bit buffer offsets)
+
+
 def _pad64(c: int) -> int:
     return (c + 63) // 64 * 64
 
@@ -233,10 +236,20 @@ class Tape:
                 wt = _dgrad_weight(w, R, self.wcache)
                 Ct = wt.shape[0]
                 if stride == 2:
-                    z = ops.new_act(x.a.N, x.a.H, x.a.W, Cout, dy.device)
-                    _l.check(_l.load().ccnet_resample_bwd_bf16(dy.data_ptr(), dy.stride(0), z.t.data_ptr(), z.ld, x.a.N, x.a.H,
-                                                               x.a.W, y.H, y.W, Cout, 1, _stream()), "zero_stuff")
-                    dxa = ops.conv(z, wt, None, Ct, R=R, pad=pad, scale=scale)
+                    # dY zero-stuffed to the input resolution, images in chunks that stay under the conv kernel's 2 GiB
+                    # operand limit (the conditioning embedding's 512^2 -> 256^2 layer at batch 32: 2.1 GB in one piece)
+                    hw_o, hw_i = y.H * y.W, x.a.H * x.a.W
+                    nchunk = max(1, min(x.a.N, (_OPERAND_LIMIT - 2 * Cout) // (hw_i * Cout * 2)))
+                    dxa = ops.new_act(x.a.N, x.a.H, x.a.W, Ct, dy.device)
+                    for n0 in range(0, x.a.N, nchunk):
+                        n1 = min(x.a.N, n0 + nchunk)
+                        z = ops.new_act(n1 - n0, x.a.H, x.a.W, Cout, dy.device)
+                        dyc = dy[n0 * hw_o:n1 * hw_o]
+                        _l.check(_l.load().ccnet_resample_bwd_bf16(dyc.data_ptr(), dy.stride(0), z.t.data_ptr(), z.ld, n1 - n0,
+                                                                   x.a.H, x.a.W, y.H, y.W, Cout, 1, _stream()), "zero_stuff")
+                        ops.conv(z, wt, None, Ct, R=R, pad=pad, scale=scale,
+                                 out=Act(dxa.t[n0 * hw_i:n1 * hw_i], n1 - n0, x.a.H, x.a.W, Ct))
+                        del z
                 elif ups == 2:
                     du = ops.conv(dya, wt, None, Ct, R=R, pad=pad, scale=scale)  # at the upsampled resolution
                     dxa = ops.new_act(x.a.N, x.a.H, x.a.W, Ct, dy.device)

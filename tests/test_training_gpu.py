@@ -102,6 +102,29 @@ def test_conv_backward(cuda, case):
         assert rel_l2(drv, rvr.grad) < 2e-2, "time-embedding-row gradient"
 
 
+def test_conv_backward_stride2_in_image_chunks(cuda, monkeypatch):
+    """The stride-2 input gradient takes its zero-stuffed dY in image chunks when one piece would pass the conv kernel's
+    2 GiB operand limit (conditioning embedding, 512^2 -> 256^2, batch 32): with the limit lowered so that 3 images run as
+    chunks of one, the result equals the one-piece result bit for bit."""
+    ops, tr, Act = _mods()
+    N, H, C, Cout = 3, 16, 64, 64
+    g = torch.Generator().manual_seed(77)
+    x = _bf(torch.randn(N * H * H, C, generator=g)).to(cuda)
+    w = _bf(torch.randn(Cout, 9 * C, generator=g) / math.sqrt(9 * C)).to(cuda)
+    dy = _bf(torch.randn(N * (H // 2) ** 2, Cout, generator=g)).to(cuda)
+
+    def run():
+        T = tr.Tape()
+        xv = tr.Var(Act(x, N, H, H, C), True)
+        out = T.conv(xv, w, None, Cout, R=3, stride=2)
+        out.g = dy
+        T.backward()
+        return xv.g.clone()
+    whole = run()
+    monkeypatch.setattr(tr, "_OPERAND_LIMIT", H * H * Cout * 2 + 2 * Cout + 1)
+    assert torch.equal(run(), whole)
+
+
 @pytest.mark.parametrize("N,H,C1,C2,groups,silu", [(2, 16, 64, 0, 32, True), (2, 8, 128, 64, 32, True), (3, 8, 320, 0, 32, False),
                                                     (1, 16, 64, 64, 32, False)])
 def test_groupnorm_backward(cuda, N, H, C1, C2, groups, silu):
