@@ -314,7 +314,7 @@ def main():
                 "traffic_source": (traffic or {}).get("source"),
                 # inputs once + weights once + outputs (+ residual operands), averaged over this pass's launches
                 "algorithmic_bytes": round(alg_per_launch),
-                "traffic_over_algorithmic": round(tb / alg_per_launch, 2) if tb else None,
+                "traffic_over_algorithmic": round(tb / alg_per_launch, 3) if tb else None,
                 "algorithmic_gbps": round(alg_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                 "launches": int(launches), "kernel_ms_total": round(ms, 3),
                 "avg_launch_us": round(ms * 1e3 / max(launches, 1), 2),
