@@ -1131,6 +1131,7 @@ struct PwArgs {
     const __bf16* x; const __bf16* w; const float* bias; const __bf16* res; __bf16* out;
     int M, ldx, ldw, ldres, ldo, chunks, chunks_per_block;
     int G;  // cout groups (Cout <= 32 WAVES G): G blocks walk the same row range, one group each
+    int per, total;  // per > 0: the one-round layout for a G that does not divide an XCD's CUs (see try_pw320)
     int Cout;  // (GEGLU: rows of w; the last group may be partial: its waves beyond Cout only stage rows and meet the barriers)
     unsigned x_bytes;
     const float* colsum; float ln_eps;  // LNF
@@ -1154,7 +1155,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void pw_stream_kernel(const PwArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int bt = blockIdx.x >> 3, grp = bt % a.G, range = (bt / a.G) * 8 + (blockIdx.x & 7);
+    int bt = blockIdx.x >> 3, grp = bt % a.G, range = (bt / a.G) * 8 + (blockIdx.x & 7);
+    if (a.per) {  // one round of floor(CUs / G) ranges: XCD x takes the (range, group) pairs x per .. x per + per - 1
+        bt = (blockIdx.x & 7) * a.per + bt;
+        if (bt >= a.total) return;  // (whole block: no barrier is pending)
+        range = bt / a.G;
+        grp = bt - range * a.G;
+    }
     const int c_lo = range * a.chunks_per_block;
     const int c_hi = min(c_lo + a.chunks_per_block, a.chunks);
     if (c_lo >= c_hi) return;  // (whole block: no barrier is pending)
@@ -1394,6 +1401,7 @@ int g_dbg_zero = 0;    // timing experiments only: bit0 = x descriptors empty, b
 constexpr int kNumCUs = 256;
 int g_persist = 1;  // tuning: 0 = persistent configurations launch one block per tile
 
+int g_pw_ranges = 0;  // tuning (ccnet_set_option key 11): row ranges of the many-group streaming launches (0 = 64)
 int g_pw320 = 31;  // tuning (ccnet_set_option key 8): 0 = these layers run on the tiled kernel; bit 1: several cout groups too;
                    // bit 2: GEGLU too; bit 3: 640 input channels too (8 waves x 160 weight registers, 256 couts per block);
                    // bit 4: LayerNorm statistics in the kernel (colsum without rowstat)
@@ -1442,10 +1450,23 @@ int try_pw320(const ccnet_conv_params* p, int M, hipStream_t st, bool* done) {
     // (one round of 8 floor(256 / 8 G) x G blocks measured 2-4 % faster than 256 or 128 ranges in three or four rounds: fewer
     // weight prologues)
     int ranges = 8 * (kNumCUs / (8 * G));
-    if (ranges * G < 208) ranges = 64;   // (many groups: several rounds of 64 ranges x G blocks)
+    int grid = ranges * G;
+    if (ranges * G < 208) {
+        // G does not fill the XCDs in units of 8 ranges (20 groups at ff.linear1 + GEGLU of the 32x32 level): still ONE round --
+        // floor(CUs / G) ranges, the (range, group) pairs dealt to the XCDs in runs, so that a range's blocks sit on one XCD
+        // (a run boundary splits every third range over two).  Rounds of 64 ranges cost a weight prologue per round and block:
+        // 236 us (five rounds) / 200 us (24 ranges, two rounds) / 228 us on 160 CUs (8 ranges, one round) at 32768 x 5120 x 640.
+        ranges = g_pw_ranges > 0 ? g_pw_ranges : kNumCUs / G;
+        if (g_pw_ranges > 0 && (ranges % 8) == 0) {
+            grid = ranges * G;  // (the multi-round form, for A/B)
+        } else {
+            a.total = ranges * G;
+            a.per = (a.total + 7) / 8;
+            grid = 8 * a.per;
+        }
+    }
     a.chunks_per_block = (a.chunks + ranges - 1) / ranges;
     a.x_bytes = (unsigned)xb;
-    const int grid = ranges * G;
     a.colsum = p->colsum; a.ln_eps = p->ln_eps;
     const int rc = lnf ? launch_pw<320, 10, 4, false, false, true>(a, grid, st)
                  : c640 ? (p->act == 2 ? launch_pw<640, 8, 3, false, true>(a, grid, st)
@@ -1702,6 +1723,7 @@ extern "C" int ccnet_set_option(int key, int value) {
     if (key == 8) { g_pw320 = value; return CCNET_OK; }
     if (key == 9) { g_m16 = value; return CCNET_OK; }
     if (key == 10) { g_korder = value; return CCNET_OK; }
+    if (key == 11) { g_pw_ranges = value; return CCNET_OK; }
     return CCNET_EINVAL;
 }
 

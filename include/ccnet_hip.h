@@ -320,7 +320,8 @@ int ccnet_to_uint8(const float* x, int N, int C, int HW, int f32_scale, uint8_t*
  * statistics in the kernel: without it a colsum-only problem returns CCNET_EUNSUP), 9 the 16x16x32-MFMA instances of the tile
  * kernel (0: every launch on the 32x32x16 instances), 2 = 2 also selects the windowed tile walk, 10 the K walk of the 3x3
  * convolutions on those instances (0 (tap, channel chunk), 1 (channel chunk, tap), -1 per layer: the walk changes, the weight
- * image does not).  Results do not depend on any of them beyond the order of fp32 sums inside a tile (the streaming kernel is
+ * image does not), 11 the row ranges of a streaming launch whose cout groups do not fill the XCDs in units of eight ranges
+ * (0: one round of floor(CUs / groups) ranges; a multiple of 8: that many ranges in several rounds).  Results do not depend on any of them beyond the order of fp32 sums inside a tile (the streaming kernel is
  * bit-identical to the tiled one). */
 int ccnet_set_option(int key, int value);
 int ccnet_prof_enable(int on);
