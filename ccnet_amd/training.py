@@ -104,7 +104,7 @@ def _gemm_nt(a: torch.Tensor, b: torch.Tensor, scale: float = 1.0, nb: int = 1) 
     p.ldx1 = a.stride(0); p.ldw = b.stride(0); p.ldo = Rb; p.scale = scale; p.batch = nb
     p.sx1 = Kc; p.sw = Kc; p.so = Ra * Rb
     ops._launch_conv(p, a.device, "weight-gradient GEMM")
-    return out.float().sum(0)
+    return out.sum(0, dtype=torch.float32)  # (bf16 partials, fp32 accumulation: no fp32 copy of the partials)
 
 
 def _plan_wgrad(M: int, Ra: int, Rb: int) -> Tuple[int, int]:
