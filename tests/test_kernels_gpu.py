@@ -85,6 +85,7 @@ def test_conv_gemm(cuda, case):
                                   (16, 64, False, 0, 2560, 2, 320), (18, 64, False, 64, 2560, 2, 320),
                                   (17, 63, True, 0, 320, 0, 320), (17, 63, False, 0, 960, 0, 320), (17, 63, False, 0, 2560, 2, 320),
                                   (32, 32, False, 0, 1920, 0, 640), (33, 31, False, 64, 1920, 0, 640), (34, 32, False, 0, 5120, 2, 640),
+                                  (35, 31, False, 0, 5120, 2, 640),  # 20 cout groups: one round of 12 row ranges, ragged rows
                                   (32, 32, True, 0, 1280, 0, 640)])
 def test_pointwise_streaming_kernel(cuda, case):
     """1x1 layers with 320 input channels at the 64x64 level (o-proj / proj_in / proj_out / to_q, qkv, ff.linear1 +
